@@ -1,0 +1,107 @@
+"""ctypes binding of libcat_hip.so (include/cat_hip.h).
+
+The product path has NO fallback: if the shared object is missing the import raises, and every wrapper raises
+RuntimeError with cat_hip_last_error() when a kernel entry point reports a failure."""
+import ctypes as C
+import os
+
+from . import _build
+
+c_f = C.c_float
+c_i = C.c_int
+c_l = C.c_int64
+c_p = C.c_void_p
+
+
+class ConvGeom(C.Structure):
+    _fields_ = [(n, c_i) for n in ('N', 'H', 'W', 'Cin', 'xcs', 'Ho', 'Wo', 'Cout', 'ycs', 'kh', 'kw', 'stride', 'pad',
+                                   'pad_mode', 'act')] + [('slope', c_f), ('ycw', c_i)]
+
+
+class NormGeom(C.Structure):
+    _fields_ = [('N', c_i), ('HW', c_i), ('C', c_i), ('cs', c_i), ('mode', c_i), ('eps', c_f), ('momentum', c_f),
+                ('act', c_i), ('slope', c_f)]
+
+
+PAD_ZERO, PAD_REFLECT = 0, 1
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
+NORM_INSTANCE, NORM_BATCH = 0, 1
+LOSS_L1, LOSS_LSGAN, LOSS_HINGE_D_REAL, LOSS_HINGE_D_FAKE, LOSS_NEG_MEAN, LOSS_MSE = range(6)
+
+_G, _NG = C.POINTER(ConvGeom), C.POINTER(NormGeom)
+# name -> (restype, argtypes); mirrors include/cat_hip.h one to one (tests check every symbol is exported)
+SIGNATURES = {
+    'cat_hip_last_error': (C.c_char_p, []),
+    'cat_hip_version': (c_i, []),
+    'cat_conv2d_fwd': (c_i, [_G, c_p, c_p, c_p, c_p, c_p]),
+    'cat_conv2d_dgrad': (c_i, [_G, c_p, c_p, c_p, c_p, c_i, c_i, c_p]),
+    'cat_conv2d_wgrad_ws_bytes': (C.c_size_t, [_G]),
+    'cat_conv2d_wgrad': (c_i, [_G, c_p, c_p, c_p, c_i, c_p, c_p]),
+    'cat_dwconv2d_fwd': (c_i, [_G, c_p, c_p, c_p, c_p, c_p]),
+    'cat_dwconv2d_dgrad': (c_i, [_G, c_p, c_p, c_p, c_i, c_p]),
+    'cat_dwconv2d_wgrad': (c_i, [_G, c_p, c_p, c_p, c_i, c_p, c_p]),
+    'cat_dwconv2d_wgrad_ws_bytes': (C.c_size_t, [_G]),
+    'cat_reflect_pad_bwd': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    'cat_channel_sum': (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p]),
+    'cat_channel_sum_ws_bytes': (C.c_size_t, [c_i, c_i]),
+    'cat_norm_ws_bytes': (C.c_size_t, [_NG]),
+    'cat_norm_fwd': (c_i, [_NG, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    'cat_norm_bwd': (c_i, [_NG, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p]),
+    'cat_bn_fold': (c_i, [c_p, c_p, c_p, c_p, c_f, c_i, c_p, c_p, c_p]),
+    'cat_affine_act_fwd': (c_i, [c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_f, c_p]),
+    'cat_act_fwd': (c_i, [c_p, c_p, c_l, c_i, c_f, c_p]),
+    'cat_act_bwd': (c_i, [c_p, c_p, c_p, c_l, c_i, c_f, c_p]),
+    'cat_add_n': (c_i, [C.POINTER(c_p), c_i, c_p, c_l, c_p]),
+    'cat_concat2': (c_i, [c_p, c_i, c_i, c_p, c_i, c_i, c_p, c_i, c_l, c_p]),
+    'cat_slice_channels': (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_l, c_p]),
+    'cat_nchw_to_nhwc': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
+    'cat_nhwc_to_nchw': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
+    'cat_ka_ws_bytes': (C.c_size_t, [c_i]),
+    'cat_ka_fwd': (c_i, [c_p, c_l, c_p, c_l, c_i, c_p, c_p, c_p]),
+    'cat_ka_bwd': (c_i, [c_p, c_l, c_i, c_p, c_p, c_p, c_p]),
+    'cat_loss_ws_bytes': (C.c_size_t, [c_l]),
+    'cat_loss_fwd': (c_i, [c_i, c_p, c_p, c_f, c_l, c_i, c_i, c_p, c_p, c_p]),
+    'cat_loss_bwd': (c_i, [c_i, c_p, c_p, c_f, c_l, c_i, c_i, c_p, c_f, c_p, c_p]),
+    'cat_adam_step': (c_i, [c_p, c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_f, c_i, c_f, c_p]),
+    'cat_fill': (c_i, [c_p, c_l, c_f, c_p]),
+    'cat_axpy': (c_i, [c_p, c_p, c_l, c_f, c_p]),
+}
+
+_lib = None
+
+
+def lib_path():
+    return _build.LIB
+
+
+def load():
+    """dlopen the in-tree library (never builds implicitly on a GPU box: build() is the build step)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise RuntimeError(f'{path} is missing: run `python -c "import __graft_entry__ as g; g.build()"` '
+                           '(cat_amd has no CPU / eager fallback)')
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error():
+    return load().cat_hip_last_error().decode()
+
+
+def call(name, *args):
+    """Call an int-returning entry point, raise on failure."""
+    rc = getattr(load(), name)(*args)
+    if rc != 0:
+        raise RuntimeError(f'{name} failed ({rc}): {last_error()}')
+
+
+def query(name, *args):
+    return getattr(load(), name)(*args)

@@ -1,0 +1,64 @@
+// Shared device/host helpers for libcat_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/cat_hip.h"
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+namespace cat {
+
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+#define CAT_REQUIRE(cond, ...)            \
+  do {                                    \
+    if (!(cond)) {                        \
+      cat::set_error(__VA_ARGS__);        \
+      return -22;                         \
+    }                                     \
+  } while (0)
+
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+__device__ __forceinline__ float apply_act(float v, int act, float slope) {
+  switch (act) {
+    case CAT_ACT_RELU: return v > 0.f ? v : 0.f;
+    case CAT_ACT_LRELU: return v > 0.f ? v : v * slope;
+    case CAT_ACT_TANH: return tanhf(v);
+    default: return v;
+  }
+}
+
+// derivative of the activation expressed through its OUTPUT y (all four are invertible enough for that)
+__device__ __forceinline__ float act_grad_from_out(float y, int act, float slope) {
+  switch (act) {
+    case CAT_ACT_RELU: return y > 0.f ? 1.f : 0.f;
+    case CAT_ACT_LRELU: return y > 0.f ? 1.f : slope;
+    case CAT_ACT_TANH: return 1.f - y * y;
+    default: return 1.f;
+  }
+}
+
+__device__ __forceinline__ int reflect_idx(int i, int n) {
+  i = i < 0 ? -i : i;
+  return i >= n ? 2 * n - 2 - i : i;
+}
+
+// XCD-aware, bijective block remap (guide §5 T1): consecutive logical tiles land on one XCD's L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7;
+  const int xcd = bid & 7, idx = bid >> 3;
+  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+}  // namespace cat

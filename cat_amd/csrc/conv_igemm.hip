@@ -1,0 +1,636 @@
+// Implicit-GEMM convolution for gfx950 on the exact-fp32 MFMA (v_mfma_f32_16x16x4_f32), NHWC.
+//
+//   fwd   : y[M = N*Ho*Wo][Cout]      = im2col(x)[M][K] * W^T[K][Cout]          K = kh*kw*cin4
+//   dgrad : dx[M = class pixels][Cin] = col(dy)[M][K']  * Wt[K'][Cin]           K' = taps(class)*cout4
+//           (stride-2 problems are split into stride*stride parity classes so that no MFMA work is spent on
+//            taps that cannot contribute; the same kernel is nn.ConvTranspose2d's forward)
+//   wgrad : dw[Cout][K]               = dy^T[Cout][M] * im2col(x)[M][K]          split over M, partials in ws
+//
+// One workgroup = 256 threads = 4 wave64, one wave per SIMD; wave tile = (MT*16) x (NT*16) accumulators of
+// 16x16x4 MFMAs; BK = 16.  Operand tiles are staged global -> VGPR -> LDS with a one-chunk register prefetch
+// (loads for chunk t+1 are in flight while chunk t is on the matrix pipe), LDS is double buffered, one barrier per
+// chunk.  "K-contiguous" tiles ([row][16 k]) use an XOR swizzle that is conflict-free for both the float4 store
+// (row = tid>>2, quad = tid&3) and the ds_read_b128 fragment read (row = lane&15, quad = lane>>4);
+// "N-contiguous" tiles ([16 k][cols + 4]) are read with ds_read_b32 at a row stride == 4 (mod 8) floats.
+// Ragged channel counts (pruned students: 4..17, 56, 82 ...) never touch HBM layout beyond the 4-float pixel
+// stride: the N edge is handled by 16-wide tile variants chosen per layer, the K edge by zero-filled quads.
+#include "common.h"
+
+namespace {
+
+using cat::cdiv;
+
+struct IgemmArgs {
+  const float* a;     // activation operand (x for fwd/wgrad, dy for dgrad)
+  const float* b;     // weights (fwd/dgrad) or dy (wgrad)
+  const float* bias;  // optional
+  float* out;         // y / dx / dw-or-workspace
+  int N, H, W, Cin, xcs;
+  int Ho, Wo, Cout, ycs;
+  int kh, kw, stride, pad, reflect;
+  int act;
+  float slope;
+  int cw;        // channels [Cvalid, cw) of the output pixel get zeros
+  int c4;        // per-tap K extent (cin4 for fwd/wgrad, cout4 for dgrad)
+  int K;         // fwd/wgrad: kh*kw*cin4
+  int M;         // fwd/wgrad: N*Ho*Wo
+  int wvec;      // weight rows can be read as float4
+  // dgrad
+  int Hin, Win, pad_eff, ocs;
+  // wgrad
+  int nsplit, mchunk, direct, accumulate;
+};
+
+__device__ __forceinline__ int swz(int r, int q) { return (r * 4 + (q ^ ((r >> 1) & 3))) * 4; }
+
+__device__ __forceinline__ f4 ldg4(const float* p) { return *reinterpret_cast<const f4*>(p); }
+
+template <int MT, int NT>
+__device__ __forceinline__ void mma_kcontig_a_kcontig_b(const float* A, const float* B, int arow0, int brow0, int lane,
+                                                       f4 (&acc)[MT][NT]) {
+  const int lr = lane & 15, lq = lane >> 4;
+  f4 fa[MT], fb[NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const f4*>(A + swz(arow0 + i * 16 + lr, lq));
+#pragma unroll
+  for (int j = 0; j < NT; ++j) fb[j] = *reinterpret_cast<const f4*>(B + swz(brow0 + j * 16 + lr, lq));
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][t], fb[j][t], acc[i][j], 0, 0, 0);
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+template <int MT, int NT, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_fwd_kernel(IgemmArgs p) {
+  constexpr int BM = WM * MT * 16, BN = WN * NT * 16;
+  constexpr int AI = BM / 64, BI = (BN + 63) / 64;
+  __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * 16];
+  float* sA = smem;
+  float* sB = smem + 2 * BM * 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int ntn = (p.Cout + BN - 1) / BN;
+  const int bid = cat::xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (bid / ntn) * BM, n0 = (bid % ntn) * BN;
+  const int q = tid & 3, r0 = tid >> 2;
+  const int HoWo = p.Ho * p.Wo;
+  const int taps = p.kh * p.kw;
+
+  int iy0[AI], ix0[AI];
+  int64_t xoff[AI];
+  bool rv[AI];
+#pragma unroll
+  for (int i = 0; i < AI; ++i) {
+    const int m = m0 + r0 + 64 * i;
+    rv[i] = m < p.M;
+    const int mm = rv[i] ? m : 0;
+    const int n = mm / HoWo, rem = mm - n * HoWo;
+    const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+    iy0[i] = oy * p.stride - p.pad;
+    ix0[i] = ox * p.stride - p.pad;
+    xoff[i] = (int64_t)n * p.H * p.W * p.xcs;
+  }
+  const float* wrow[BI];
+  bool bv[BI];
+#pragma unroll
+  for (int i = 0; i < BI; ++i) {
+    const int r = r0 + 64 * i, co = n0 + r;
+    bv[i] = r < BN && co < p.Cout;
+    wrow[i] = p.b + (int64_t)(bv[i] ? co : 0) * taps * p.Cin;
+  }
+
+  f4 ra[AI], rb[BI];
+  auto gload = [&](int kc) {
+    const int k = kc * 16 + q * 4;
+    const bool kv = k < p.K;
+    const int tap = kv ? k / p.c4 : 0, ci = kv ? k - tap * p.c4 : 0;
+    const int ky = tap / p.kw, kx = tap - ky * p.kw;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      int iy = iy0[i] + ky, ix = ix0[i] + kx;
+      bool v = rv[i] && kv;
+      if (p.reflect) {
+        iy = cat::reflect_idx(iy, p.H);
+        ix = cat::reflect_idx(ix, p.W);
+      } else {
+        v = v && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      }
+      ra[i] = v ? ldg4(p.a + xoff[i] + ((int64_t)iy * p.W + ix) * p.xcs + ci) : f4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      const float* wp = wrow[i] + (int64_t)tap * p.Cin + ci;
+      f4 v = {0.f, 0.f, 0.f, 0.f};
+      if (bv[i] && kv) {
+        if (p.wvec) {
+          v = ldg4(wp);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (ci + e < p.Cin) v[e] = wp[e];
+        }
+      }
+      rb[i] = v;
+    }
+  };
+  auto sstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < AI; ++i) *reinterpret_cast<f4*>(sA + buf * BM * 16 + swz(r0 + 64 * i, q)) = ra[i];
+#pragma unroll
+    for (int i = 0; i < BI; ++i)
+      if (r0 + 64 * i < BN) *reinterpret_cast<f4*>(sB + buf * BN * 16 + swz(r0 + 64 * i, q)) = rb[i];
+  };
+
+  f4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (p.K + 15) >> 4;
+  gload(0);
+  sstore(0);
+  __syncthreads();
+  for (int kc = 0; kc < nk; ++kc) {
+    const int buf = kc & 1;
+    if (kc + 1 < nk) gload(kc + 1);
+    mma_kcontig_a_kcontig_b<MT, NT>(sA + buf * BM * 16, sB + buf * BN * 16, wm * MT * 16, wn * NT * 16, lane, acc);
+    if (kc + 1 < nk) sstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  const int lr = lane & 15, lq = lane >> 4;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int col = n0 + wn * NT * 16 + j * 16 + lr;
+    const bool cvalid = col < p.Cout;
+    const float bias = (cvalid && p.bias) ? p.bias[col] : 0.f;
+    if (!cvalid && col >= p.cw) continue;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int m = m0 + wm * MT * 16 + i * 16 + lq * 4 + rg;
+        if (m < p.M) p.out[(int64_t)m * p.ycs + col] = cvalid ? cat::apply_act(acc[i][j][rg] + bias, p.act, p.slope) : 0.f;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ dgrad
+// blockIdx.y = parity class (py, px) of the forward stride.  N dimension = Cin, K = taps(class) * cout4.
+template <int MT, int NT, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_dgrad_kernel(IgemmArgs p) {
+  constexpr int BM = WM * MT * 16, BN = WN * NT * 16, LDB = BN + 4;
+  constexpr int AI = BM / 64;
+  constexpr int BQ = BN / 4;                 // float4 per k-row of the B tile
+  constexpr int BI = (16 * BQ + 255) / 256;  // float4 per thread
+  __shared__ __attribute__((aligned(16))) float smem[2 * (BM * 16 + 16 * LDB)];
+  float* sA = smem;
+  float* sB = smem + 2 * BM * 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int s = p.stride;
+  const int py = blockIdx.y / s, px = blockIdx.y % s;
+  // pixels of this class in the (possibly padded) input plane
+  const int iyf = ((py - p.pad_eff) % s + s) % s, ixf = ((px - p.pad_eff) % s + s) % s;
+  const int Hc = iyf < p.Hin ? (p.Hin - iyf + s - 1) / s : 0, Wc = ixf < p.Win ? (p.Win - ixf + s - 1) / s : 0;
+  const int cy0 = (iyf + p.pad_eff - py) / s, cx0 = (ixf + p.pad_eff - px) / s;
+  const int nty = py < p.kh ? (p.kh - py + s - 1) / s : 0, ntx = px < p.kw ? (p.kw - px + s - 1) / s : 0;
+  const int K = nty * ntx * p.c4;
+  const int Mc = p.N * Hc * Wc;
+  const int ntn = (p.Cin + BN - 1) / BN;
+  const int bid = cat::xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (bid / ntn) * BM, n0 = (bid % ntn) * BN;
+  if (m0 >= Mc) return;
+  const int q = tid & 3, r0 = tid >> 2;
+  const int HcWc = Hc * Wc;
+  const int taps = p.kh * p.kw;
+
+  int cy[AI], cx[AI];
+  int64_t aoff[AI];
+  bool rv[AI];
+#pragma unroll
+  for (int i = 0; i < AI; ++i) {
+    const int m = m0 + r0 + 64 * i;
+    rv[i] = m < Mc;
+    const int mm = rv[i] ? m : 0;
+    const int n = mm / HcWc, rem = mm - n * HcWc;
+    const int a = rem / Wc, b = rem - a * Wc;
+    cy[i] = cy0 + a;
+    cx[i] = cx0 + b;
+    aoff[i] = (int64_t)n * p.Ho * p.Wo * p.ycs;
+  }
+
+  f4 ra[AI], rb[BI];
+  auto gload = [&](int kc) {
+    {
+      const int k = kc * 16 + q * 4;
+      const bool kv = k < K;
+      const int tj = kv ? k / p.c4 : 0, co = kv ? k - tj * p.c4 : 0;
+      const int jy = ntx ? tj / ntx : 0, jx = tj - jy * ntx;
+#pragma unroll
+      for (int i = 0; i < AI; ++i) {
+        const int oy = cy[i] - jy, ox = cx[i] - jx;
+        const bool v = rv[i] && kv && (unsigned)oy < (unsigned)p.Ho && (unsigned)ox < (unsigned)p.Wo;
+        ra[i] = v ? ldg4(p.a + aoff[i] + ((int64_t)oy * p.Wo + ox) * p.ycs + co) : f4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      const int idx = tid + 256 * i;
+      const int kr = idx / BQ, nq = idx - kr * BQ;
+      f4 v = {0.f, 0.f, 0.f, 0.f};
+      const int k = kc * 16 + kr;
+      if (kr < 16 && k < K) {
+        const int tj = k / p.c4, co = k - tj * p.c4;
+        const int jy = tj / ntx, jx = tj - jy * ntx;
+        const int ky = py + jy * s, kx = px + jx * s;
+        const int ci = n0 + nq * 4;
+        if (co < p.Cout && ci < p.Cin) {
+          const float* wp = p.b + ((int64_t)co * taps + ky * p.kw + kx) * p.Cin + ci;
+          if (p.wvec) {
+            v = ldg4(wp);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (ci + e < p.Cin) v[e] = wp[e];
+          }
+        }
+      }
+      rb[i] = v;
+    }
+  };
+  auto sstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < AI; ++i) *reinterpret_cast<f4*>(sA + buf * BM * 16 + swz(r0 + 64 * i, q)) = ra[i];
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      const int idx = tid + 256 * i;
+      const int kr = idx / BQ, nq = idx - kr * BQ;
+      if (kr < 16) *reinterpret_cast<f4*>(sB + buf * 16 * LDB + kr * LDB + nq * 4) = rb[i];
+    }
+  };
+
+  f4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+
+  const int lr = lane & 15, lq = lane >> 4;
+  const int nk = (K + 15) >> 4;
+  if (nk > 0) {
+    gload(0);
+    sstore(0);
+  }
+  __syncthreads();
+  for (int kc = 0; kc < nk; ++kc) {
+    const int buf = kc & 1;
+    if (kc + 1 < nk) gload(kc + 1);
+    {
+      const float* A = sA + buf * BM * 16;
+      const float* B = sB + buf * 16 * LDB;
+      f4 fa[MT];
+      float fb[NT][4];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const f4*>(A + swz(wm * MT * 16 + i * 16 + lr, lq));
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) fb[j][t] = B[(lq * 4 + t) * LDB + wn * NT * 16 + j * 16 + lr];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][t], fb[j][t], acc[i][j], 0, 0, 0);
+    }
+    if (kc + 1 < nk) sstore(buf ^ 1);
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      const int m = m0 + wm * MT * 16 + i * 16 + lq * 4 + rg;
+      if (m >= Mc) continue;
+      const int n = m / HcWc, rem = m - n * HcWc;
+      const int a = rem / Wc, b = rem - a * Wc;
+      float* orow = p.out + (((int64_t)n * p.Hin + (iyf + a * s)) * p.Win + (ixf + b * s)) * p.ocs;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int col = n0 + wn * NT * 16 + j * 16 + lr;
+        if (col < p.Cin) {
+          const float bias = p.bias ? p.bias[col] : 0.f;
+          orow[col] = cat::apply_act(acc[i][j][rg] + bias, p.act, p.slope);
+        } else if (col < p.cw) {
+          orow[col] = 0.f;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ wgrad
+// rows = Cout (BM), cols = K = taps*cin4 (BN), reduction over the pixels [y*mchunk, (y+1)*mchunk).
+template <int MT, int NT, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(IgemmArgs p) {
+  constexpr int BM = WM * MT * 16, BN = WN * NT * 16, LDA = BM + 4, LDB = BN + 4;
+  constexpr int AQ = BM / 4, BQ = BN / 4;
+  constexpr int AI = (16 * AQ + 255) / 256, BI = (16 * BQ + 255) / 256;
+  __shared__ __attribute__((aligned(16))) float smem[2 * 16 * (LDA + LDB)];
+  float* sA = smem;
+  float* sB = smem + 2 * 16 * LDA;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int ntn = (p.K + BN - 1) / BN;
+  const int c0 = (blockIdx.x / ntn) * BM, k0 = (blockIdx.x % ntn) * BN;
+  const int mbeg = blockIdx.y * p.mchunk;
+  const int mend = min(p.M, mbeg + p.mchunk);
+  const int HoWo = p.Ho * p.Wo;
+  const int cout4 = (p.Cout + 3) & ~3;
+  const int taps = p.kh * p.kw;
+
+  // B' columns are fixed per thread: (tap, ci) of the im2col matrix
+  int bky[BI], bkx[BI], bci[BI], bpix[BI], bnq[BI];
+  bool bcv[BI];
+#pragma unroll
+  for (int i = 0; i < BI; ++i) {
+    const int idx = tid + 256 * i;
+    bpix[i] = idx / BQ;
+    bnq[i] = idx - bpix[i] * BQ;
+    const int k = k0 + bnq[i] * 4;
+    bcv[i] = bpix[i] < 16 && k < p.K;
+    const int tap = bcv[i] ? k / p.c4 : 0;
+    bci[i] = bcv[i] ? k - tap * p.c4 : 0;
+    bky[i] = tap / p.kw;
+    bkx[i] = tap - bky[i] * p.kw;
+  }
+  int apix[AI], acq[AI];
+  bool acv[AI];
+#pragma unroll
+  for (int i = 0; i < AI; ++i) {
+    const int idx = tid + 256 * i;
+    apix[i] = idx / AQ;
+    acq[i] = idx - apix[i] * AQ;
+    acv[i] = apix[i] < 16 && c0 + acq[i] * 4 < cout4;
+  }
+
+  f4 ra[AI], rb[BI];
+  auto gload = [&](int kc) {
+    const int mb = mbeg + kc * 16;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const int m = mb + apix[i];
+      ra[i] = (acv[i] && m < mend) ? ldg4(p.b + (int64_t)m * p.ycs + c0 + acq[i] * 4) : f4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      const int m = mb + bpix[i];
+      bool v = bcv[i] && m < mend;
+      const int mm = v ? m : 0;
+      const int n = mm / HoWo, rem = mm - n * HoWo;
+      const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+      int iy = oy * p.stride - p.pad + bky[i], ix = ox * p.stride - p.pad + bkx[i];
+      if (p.reflect) {
+        iy = cat::reflect_idx(iy, p.H);
+        ix = cat::reflect_idx(ix, p.W);
+      } else {
+        v = v && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      }
+      rb[i] = v ? ldg4(p.a + ((int64_t)n * p.H * p.W + (int64_t)iy * p.W + ix) * p.xcs + bci[i]) : f4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto sstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < AI; ++i)
+      if (apix[i] < 16) *reinterpret_cast<f4*>(sA + buf * 16 * LDA + apix[i] * LDA + acq[i] * 4) = ra[i];
+#pragma unroll
+    for (int i = 0; i < BI; ++i)
+      if (bpix[i] < 16) *reinterpret_cast<f4*>(sB + buf * 16 * LDB + bpix[i] * LDB + bnq[i] * 4) = rb[i];
+  };
+
+  f4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+
+  const int lr = lane & 15, lq = lane >> 4;
+  const int nk = mend > mbeg ? (mend - mbeg + 15) >> 4 : 0;
+  if (nk > 0) {
+    gload(0);
+    sstore(0);
+  }
+  __syncthreads();
+  for (int kc = 0; kc < nk; ++kc) {
+    const int buf = kc & 1;
+    if (kc + 1 < nk) gload(kc + 1);
+    {
+      const float* A = sA + buf * 16 * LDA;
+      const float* B = sB + buf * 16 * LDB;
+      float fa[MT][4], fb[NT][4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) fa[i][t] = A[(lq * 4 + t) * LDA + wm * MT * 16 + i * 16 + lr];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) fb[j][t] = B[(lq * 4 + t) * LDB + wn * NT * 16 + j * 16 + lr];
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][t], fb[j][t], acc[i][j], 0, 0, 0);
+    }
+    if (kc + 1 < nk) sstore(buf ^ 1);
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int k = k0 + wn * NT * 16 + j * 16 + lr;
+    if (k >= p.K) continue;
+    const int tap = k / p.c4, ci = k - tap * p.c4;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int co = c0 + wm * MT * 16 + i * 16 + lq * 4 + rg;
+        if (co >= p.Cout) continue;
+        if (p.direct) {
+          if (ci < p.Cin) p.out[((int64_t)co * taps + tap) * p.Cin + ci] = acc[i][j][rg];
+        } else {
+          p.out[((int64_t)blockIdx.y * p.Cout + co) * p.K + k] = acc[i][j][rg];
+        }
+      }
+    }
+  }
+}
+
+// dw[co][tap][ci] (+)= sum_z ws[z][co][tap*c4 + ci]
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nsplit,
+                                                           int Cout, int taps, int Cin, int c4, int K, int accumulate) {
+  const int64_t total = (int64_t)Cout * taps * Cin;
+  for (int64_t e = blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int ci = (int)(e % Cin);
+    const int64_t ct = e / Cin;
+    const int tap = (int)(ct % taps), co = (int)(ct / taps);
+    const float* src = ws + (int64_t)co * K + tap * c4 + ci;
+    float s = 0.f;
+    for (int z = 0; z < nsplit; ++z) s += src[(int64_t)z * Cout * K];
+    dw[e] = accumulate ? dw[e] + s : s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+#define DISPATCH_TILE_N(n, LAUNCH)   \
+  do {                               \
+    if ((n) <= 16) {                 \
+      LAUNCH(4, 1, 4, 1);            \
+    } else if ((n) <= 32) {          \
+      LAUNCH(4, 2, 4, 1);            \
+    } else if ((n) <= 48) {          \
+      LAUNCH(2, 3, 4, 1);            \
+    } else if ((n) <= 64) {          \
+      LAUNCH(2, 4, 4, 1);            \
+    } else if ((n) <= 96) {          \
+      LAUNCH(2, 6, 4, 1);            \
+    } else {                         \
+      LAUNCH(4, 4, 2, 2);            \
+    }                                \
+  } while (0)
+
+int fill_common(IgemmArgs& a, const cat_conv_t* g) {
+  CAT_REQUIRE(g->N > 0 && g->H > 0 && g->W > 0 && g->Cin > 0 && g->Cout > 0, "conv: empty geometry");
+  CAT_REQUIRE(g->stride == 1 || g->stride == 2, "conv: stride %d unsupported", g->stride);
+  CAT_REQUIRE(g->xcs % 4 == 0 && g->ycs % 4 == 0, "conv: pixel strides must be multiples of 4 (xcs=%d ycs=%d)", g->xcs, g->ycs);
+  CAT_REQUIRE(g->xcs >= ((g->Cin + 3) & ~3) && g->ycs >= ((g->Cout + 3) & ~3), "conv: pixel stride smaller than padded channel count");
+  CAT_REQUIRE(g->Ho == (g->H + 2 * g->pad - g->kh) / g->stride + 1 && g->Wo == (g->W + 2 * g->pad - g->kw) / g->stride + 1,
+              "conv: output size (%d,%d) inconsistent with geometry", g->Ho, g->Wo);
+  CAT_REQUIRE(g->pad_mode == CAT_PAD_ZERO || (g->pad < g->H && g->pad < g->W), "conv: reflect pad must be < input size");
+  a.N = g->N; a.H = g->H; a.W = g->W; a.Cin = g->Cin; a.xcs = g->xcs;
+  a.Ho = g->Ho; a.Wo = g->Wo; a.Cout = g->Cout; a.ycs = g->ycs;
+  a.kh = g->kh; a.kw = g->kw; a.stride = g->stride; a.pad = g->pad; a.reflect = g->pad_mode == CAT_PAD_REFLECT;
+  a.act = g->act; a.slope = g->slope;
+  a.wvec = (g->Cin % 4) == 0;
+  a.M = g->N * g->Ho * g->Wo;
+  return 0;
+}
+
+struct WgradPlan { int nsplit, mchunk, tiles; };
+WgradPlan wgrad_plan(const cat_conv_t* g) {
+  const int Cout = g->Cout, K = g->kh * g->kw * ((g->Cin + 3) & ~3);
+  int BM, BN;
+  if (Cout <= 16) { BM = 16; BN = 256; } else if (Cout <= 32) { BM = 32; BN = 256; } else if (Cout <= 48) { BM = 48; BN = 256; }
+  else if (Cout <= 64) { BM = 64; BN = 256; } else if (Cout <= 96) { BM = 96; BN = 128; } else { BM = 128; BN = 128; }
+  WgradPlan pl;
+  pl.tiles = cdiv(Cout, BM) * cdiv(K, BN);
+  const int M = g->N * g->Ho * g->Wo;
+  int ns = cdiv(1024, pl.tiles);
+  const int maxs = M / 256 > 0 ? M / 256 : 1;
+  if (ns > maxs) ns = maxs;
+  if (ns < 1) ns = 1;
+  pl.mchunk = cat::round_up(cdiv(M, ns), 16);
+  pl.nsplit = cdiv(M, pl.mchunk);
+  return pl;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cat_conv2d_fwd(const cat_conv_t* g, const float* x, const float* w, const float* bias, float* y, cat_stream_t stream) {
+  IgemmArgs a{};
+  if (int e = fill_common(a, g)) return e;
+  a.a = x; a.b = w; a.bias = bias; a.out = y;
+  a.c4 = (g->Cin + 3) & ~3;
+  a.K = g->kh * g->kw * a.c4;
+  a.cw = g->ycw > g->Cout ? g->ycw : g->Cout;
+  CAT_REQUIRE(a.cw <= g->ycs, "conv fwd: ycw > ycs");
+  hipStream_t s = (hipStream_t)stream;
+#define LAUNCH(MT, NT, WM, WN)                                                             \
+  {                                                                                        \
+    const int grid = cdiv(a.M, WM * MT * 16) * cdiv(a.Cout, WN * NT * 16);                 \
+    conv_fwd_kernel<MT, NT, WM, WN><<<grid, 256, 0, s>>>(a);                                \
+  }
+  DISPATCH_TILE_N(a.Cout, LAUNCH);
+#undef LAUNCH
+  return cat::check_launch("conv2d_fwd");
+}
+
+int cat_conv2d_dgrad(const cat_conv_t* g, const float* dy, const float* w, const float* bias, float* dx, int dxcs, int dxcw,
+                     cat_stream_t stream) {
+  IgemmArgs a{};
+  if (int e = fill_common(a, g)) return e;
+  a.a = dy; a.b = w; a.bias = bias; a.out = dx;
+  a.c4 = (g->Cout + 3) & ~3;
+  a.cw = dxcw > g->Cin ? dxcw : g->Cin;
+  a.ocs = dxcs;
+  CAT_REQUIRE(dxcs >= a.cw, "conv dgrad: dxcw > dxcs");
+  if (a.reflect) { a.Hin = g->H + 2 * g->pad; a.Win = g->W + 2 * g->pad; a.pad_eff = 0; }
+  else { a.Hin = g->H; a.Win = g->W; a.pad_eff = g->pad; }
+  const int st = g->stride;
+  const int mmax = g->N * cdiv(a.Hin, st) * cdiv(a.Win, st);
+  hipStream_t s = (hipStream_t)stream;
+#define LAUNCH(MT, NT, WM, WN)                                                             \
+  {                                                                                        \
+    dim3 grid(cdiv(mmax, WM * MT * 16) * cdiv(a.Cin, WN * NT * 16), st * st);              \
+    conv_dgrad_kernel<MT, NT, WM, WN><<<grid, 256, 0, s>>>(a);                              \
+  }
+  DISPATCH_TILE_N(a.Cin, LAUNCH);
+#undef LAUNCH
+  return cat::check_launch("conv2d_dgrad");
+}
+
+size_t cat_conv2d_wgrad_ws_bytes(const cat_conv_t* g) {
+  const WgradPlan pl = wgrad_plan(g);
+  const size_t K = (size_t)g->kh * g->kw * ((g->Cin + 3) & ~3);
+  return (size_t)pl.nsplit * g->Cout * K * sizeof(float);
+}
+
+int cat_conv2d_wgrad(const cat_conv_t* g, const float* x, const float* dy, float* dw, int accumulate, void* ws,
+                     cat_stream_t stream) {
+  IgemmArgs a{};
+  if (int e = fill_common(a, g)) return e;
+  const WgradPlan pl = wgrad_plan(g);
+  a.a = x; a.b = dy;
+  a.c4 = (g->Cin + 3) & ~3;
+  a.K = g->kh * g->kw * a.c4;
+  a.nsplit = pl.nsplit; a.mchunk = pl.mchunk;
+  a.direct = (pl.nsplit == 1 && !accumulate) ? 1 : 0;
+  a.accumulate = accumulate;
+  a.out = a.direct ? dw : (float*)ws;
+  CAT_REQUIRE(a.direct || ws != nullptr, "conv wgrad: workspace required");
+  hipStream_t s = (hipStream_t)stream;
+#define LAUNCH(MT, NT, WM, WN)                                                                         \
+  {                                                                                                    \
+    dim3 grid(cdiv(a.Cout, WM * MT * 16) * cdiv(a.K, WN * NT * 16), pl.nsplit);                        \
+    conv_wgrad_kernel<MT, NT, WM, WN><<<grid, 256, 0, s>>>(a);                                          \
+  }
+  if (a.Cout <= 16) LAUNCH(1, 4, 1, 4)
+  else if (a.Cout <= 32) LAUNCH(2, 4, 1, 4)
+  else if (a.Cout <= 48) LAUNCH(3, 4, 1, 4)
+  else if (a.Cout <= 64) LAUNCH(4, 4, 1, 4)
+  else if (a.Cout <= 96) LAUNCH(6, 2, 1, 4)
+  else LAUNCH(4, 4, 2, 2)
+#undef LAUNCH
+  if (int e = cat::check_launch("conv2d_wgrad")) return e;
+  if (!a.direct) {
+    const int64_t total = (int64_t)a.Cout * a.kh * a.kw * a.Cin;
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    wgrad_reduce_kernel<<<grid, 256, 0, s>>>((const float*)ws, dw, pl.nsplit, a.Cout, a.kh * a.kw, a.Cin, a.c4, a.K, accumulate);
+    return cat::check_launch("conv2d_wgrad_reduce");
+  }
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,230 @@
+// Depthwise convolution (groups == C, stride 1, k in {1,3,5,...}), NHWC, gfx950.  HBM/L2-bound direct kernels: one lane owns
+// a float4 of channels of one pixel, the k*k taps are re-read from L1/L2 (neighbouring lanes share them), the
+// filter lives in LDS as [tap][channel] so a tap is one ds_read_b128 per lane.
+// Reference: the groups=midp ConvBNReLU conv of InvertedResidualChannels (models/modules/inception_modules.py:166-173).
+#include "common.h"
+
+namespace {
+using cat::cdiv;
+
+constexpr int MAXW = 49 * 64;  // taps * cs floats of LDS filter (k<=7, cs<=64) -- larger problems fall back to global reads
+
+struct DwArgs {
+  const float* x; const float* w; const float* bias; float* y;
+  int N, H, W, C, xcs, Ho, Wo, ycs, kh, kw, pad, reflect;
+};
+
+__device__ __forceinline__ void load_filter(float* sw, const float* w, int C, int cs, int taps) {
+  for (int i = threadIdx.x; i < taps * cs; i += 256) {
+    const int t = i / cs, c = i - t * cs;
+    sw[i] = c < C ? w[c * taps + t] : 0.f;
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs p) {
+  __shared__ __attribute__((aligned(16))) float sw[MAXW];
+  const int taps = p.kh * p.kw, nq = p.ycs / 4;
+  load_filter(sw, p.w, p.C, p.ycs, taps);
+  const int64_t total = (int64_t)p.N * p.Ho * p.Wo * nq;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int cq = (int)(i % nq);
+    int64_t r = i / nq;
+    const int ox = (int)(r % p.Wo);
+    r /= p.Wo;
+    const int oy = (int)(r % p.Ho);
+    const int n = (int)(r / p.Ho);
+    const int c = cq * 4;
+    f4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] = c + e < p.C ? p.bias[c + e] : 0.f;
+    }
+    const float* xn = p.x + (int64_t)n * p.H * p.W * p.xcs + c;
+    for (int ky = 0; ky < p.kh; ++ky) {
+      int iy = oy - p.pad + ky;
+      if (p.reflect) iy = cat::reflect_idx(iy, p.H);
+      else if ((unsigned)iy >= (unsigned)p.H) continue;
+      for (int kx = 0; kx < p.kw; ++kx) {
+        int ix = ox - p.pad + kx;
+        if (p.reflect) ix = cat::reflect_idx(ix, p.W);
+        else if ((unsigned)ix >= (unsigned)p.W) continue;
+        const f4 xv = *reinterpret_cast<const f4*>(xn + ((int64_t)iy * p.W + ix) * p.xcs);
+        const f4 wv = *reinterpret_cast<const f4*>(sw + (ky * p.kw + kx) * p.ycs + c);
+        acc += xv * wv;
+      }
+    }
+    *reinterpret_cast<f4*>(p.y + i * 4) = acc;
+  }
+}
+
+// dxp[n,py,px,c] = sum_k dy[n, py+pe-ky, px+pe-kx, c] * w[c,ky,kx]; (Hin,Win,pe) = (H+2p,W+2p,0) for reflect, (H,W,p) for zero pad.
+__global__ __launch_bounds__(256) void dw_dgrad_kernel(DwArgs p, int Hin, int Win, int pe, int dxcs) {
+  __shared__ __attribute__((aligned(16))) float sw[MAXW];
+  const int taps = p.kh * p.kw, nq = dxcs / 4;
+  load_filter(sw, p.w, p.C, dxcs, taps);
+  const int64_t total = (int64_t)p.N * Hin * Win * nq;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int cq = (int)(i % nq);
+    int64_t r = i / nq;
+    const int px = (int)(r % Win);
+    r /= Win;
+    const int py = (int)(r % Hin);
+    const int n = (int)(r / Hin);
+    const int c = cq * 4;
+    f4 acc = {0.f, 0.f, 0.f, 0.f};
+    const float* dn = p.x + (int64_t)n * p.Ho * p.Wo * p.xcs + c;  // p.x = dy here
+    for (int ky = 0; ky < p.kh; ++ky) {
+      const int oy = py + pe - ky;
+      if ((unsigned)oy >= (unsigned)p.Ho) continue;
+      for (int kx = 0; kx < p.kw; ++kx) {
+        const int ox = px + pe - kx;
+        if ((unsigned)ox >= (unsigned)p.Wo) continue;
+        const f4 gv = *reinterpret_cast<const f4*>(dn + ((int64_t)oy * p.Wo + ox) * p.xcs);
+        const f4 wv = *reinterpret_cast<const f4*>(sw + (ky * p.kw + kx) * dxcs + c);
+        acc += gv * wv;
+      }
+    }
+    *reinterpret_cast<f4*>(p.y + i * 4) = acc;
+  }
+}
+
+// dw[c][tap] partials: lanes = (pixel-lane, channel quad); each lane keeps one float4 accumulator per tap of ONE filter row
+// (blockIdx.y = ky) to bound registers at kw*4; block-reduced through LDS; partial [nb][taps][cs] in ws.
+template <int KW>
+__global__ __launch_bounds__(256) void dw_wgrad_kernel(DwArgs p, float* __restrict__ part, int nb, int ppl) {
+  __shared__ f4 red[256];
+  const int nq = p.xcs / 4;
+  const int tid = threadIdx.x, cq = tid % nq, pl = tid / nq;
+  const int ky = blockIdx.y, b = blockIdx.x;
+  const int64_t P = (int64_t)p.N * p.Ho * p.Wo;
+  const int64_t per = (P + nb - 1) / nb;
+  const int64_t pbeg = b * per, pend = pbeg + per < P ? pbeg + per : P;
+  f4 acc[KW];
+#pragma unroll
+  for (int k = 0; k < KW; ++k) acc[k] = f4{0.f, 0.f, 0.f, 0.f};
+  if (pl < ppl) {
+    for (int64_t q = pbeg + pl; q < pend; q += ppl) {
+      const int ox = (int)(q % p.Wo);
+      const int64_t r = q / p.Wo;
+      const int oy = (int)(r % p.Ho);
+      const int n = (int)(r / p.Ho);
+      int iy = oy - p.pad + ky;
+      if (p.reflect) iy = cat::reflect_idx(iy, p.H);
+      else if ((unsigned)iy >= (unsigned)p.H) continue;
+      const f4 gv = *reinterpret_cast<const f4*>(p.y + q * p.ycs + cq * 4);  // p.y = dy here (read only)
+      const float* xr = p.x + ((int64_t)n * p.H + iy) * p.W * p.xcs + cq * 4;
+#pragma unroll
+      for (int kx = 0; kx < KW; ++kx) {
+        int ix = ox - p.pad + kx;
+        if (p.reflect) ix = cat::reflect_idx(ix, p.W);
+        else if ((unsigned)ix >= (unsigned)p.W) continue;
+        acc[kx] += gv * *reinterpret_cast<const f4*>(xr + (int64_t)ix * p.xcs);
+      }
+    }
+  }
+#pragma unroll
+  for (int kx = 0; kx < KW; ++kx) {
+    __syncthreads();
+    red[tid] = acc[kx];
+    __syncthreads();
+    if (pl == 0) {
+      f4 s = acc[kx];
+      for (int j = 1; j < ppl; ++j) s += red[j * nq + cq];
+      *reinterpret_cast<f4*>(part + ((int64_t)b * p.kh * KW + ky * KW + kx) * p.xcs + cq * 4) = s;
+    }
+  }
+}
+
+__global__ void dw_wgrad_final_kernel(const float* __restrict__ part, float* __restrict__ dw, int C, int cs, int taps, int nb,
+                                      int accumulate) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= C * taps) return;
+  const int c = i / taps, t = i - c * taps;
+  float s = 0.f;
+  for (int b = 0; b < nb; ++b) s += part[((int64_t)b * taps + t) * cs + c];
+  dw[i] = accumulate ? dw[i] + s : s;
+}
+
+int ew_grid(int64_t n) {
+  int64_t b = (n + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+
+int dw_check(const cat_conv_t* g) {
+  CAT_REQUIRE(g->Cin == g->Cout && g->stride == 1, "dwconv: needs Cin == Cout, stride 1");
+  CAT_REQUIRE(g->xcs % 4 == 0 && g->ycs % 4 == 0 && g->xcs >= g->Cin && g->ycs >= g->Cout, "dwconv: bad pixel stride");
+  CAT_REQUIRE(g->kh * g->kw * (g->xcs > g->ycs ? g->xcs : g->ycs) <= MAXW, "dwconv: filter does not fit the LDS stage (k*k*cs <= %d)", MAXW);
+  CAT_REQUIRE(g->Ho == g->H + 2 * g->pad - g->kh + 1 && g->Wo == g->W + 2 * g->pad - g->kw + 1, "dwconv: inconsistent output size");
+  CAT_REQUIRE(g->pad_mode == CAT_PAD_ZERO || (g->pad < g->H && g->pad < g->W), "dwconv: reflect pad must be < input size");
+  return 0;
+}
+
+DwArgs dw_args(const cat_conv_t* g) {
+  DwArgs a{};
+  a.N = g->N; a.H = g->H; a.W = g->W; a.C = g->Cin; a.xcs = g->xcs; a.Ho = g->Ho; a.Wo = g->Wo; a.ycs = g->ycs;
+  a.kh = g->kh; a.kw = g->kw; a.pad = g->pad; a.reflect = g->pad_mode == CAT_PAD_REFLECT;
+  return a;
+}
+
+struct DwWgPlan { int nb, ppl; };
+DwWgPlan dw_wg_plan(const cat_conv_t* g) {
+  DwWgPlan p;
+  p.ppl = 256 / (g->xcs / 4);
+  const int64_t P = (int64_t)g->N * g->Ho * g->Wo;
+  int nb = cdiv(1024, g->kh);
+  const int maxb = cdiv(P, (int64_t)p.ppl * 16);
+  if (nb > maxb) nb = maxb;
+  if (nb < 1) nb = 1;
+  p.nb = nb;
+  return p;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cat_dwconv2d_fwd(const cat_conv_t* g, const float* x, const float* w, const float* bias, float* y, cat_stream_t stream) {
+  if (int e = dw_check(g)) return e;
+  DwArgs a = dw_args(g);
+  a.x = x; a.w = w; a.bias = bias; a.y = y;
+  dw_fwd_kernel<<<ew_grid((int64_t)g->N * g->Ho * g->Wo * (g->ycs / 4)), 256, 0, (hipStream_t)stream>>>(a);
+  return cat::check_launch("dwconv2d_fwd");
+}
+
+int cat_dwconv2d_dgrad(const cat_conv_t* g, const float* dy, const float* w, float* dx, int dxcs, cat_stream_t stream) {
+  if (int e = dw_check(g)) return e;
+  CAT_REQUIRE(dxcs % 4 == 0 && dxcs >= g->Cin && g->kh * g->kw * dxcs <= MAXW, "dwconv dgrad: bad dxcs");
+  DwArgs a = dw_args(g);
+  a.x = dy; a.xcs = g->ycs; a.w = w; a.y = dx;
+  const bool refl = g->pad_mode == CAT_PAD_REFLECT;
+  const int Hin = refl ? g->H + 2 * g->pad : g->H, Win = refl ? g->W + 2 * g->pad : g->W, pe = refl ? 0 : g->pad;
+  dw_dgrad_kernel<<<ew_grid((int64_t)g->N * Hin * Win * (dxcs / 4)), 256, 0, (hipStream_t)stream>>>(a, Hin, Win, pe, dxcs);
+  return cat::check_launch("dwconv2d_dgrad");
+}
+
+size_t cat_dwconv2d_wgrad_ws_bytes(const cat_conv_t* g) {
+  return (size_t)dw_wg_plan(g).nb * g->kh * g->kw * g->xcs * sizeof(float);
+}
+
+int cat_dwconv2d_wgrad(const cat_conv_t* g, const float* x, const float* dy, float* dw, int accumulate, void* ws, cat_stream_t stream) {
+  if (int e = dw_check(g)) return e;
+  CAT_REQUIRE(ws && g->xcs == g->ycs && g->xcs <= 1024, "dwconv wgrad: needs workspace and xcs == ycs <= 1024");
+  DwArgs a = dw_args(g);
+  a.x = x; a.y = const_cast<float*>(dy);
+  const DwWgPlan pl = dw_wg_plan(g);
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(pl.nb, g->kh);
+  switch (g->kw) {
+    case 1: dw_wgrad_kernel<1><<<grid, 256, 0, s>>>(a, (float*)ws, pl.nb, pl.ppl); break;
+    case 3: dw_wgrad_kernel<3><<<grid, 256, 0, s>>>(a, (float*)ws, pl.nb, pl.ppl); break;
+    case 5: dw_wgrad_kernel<5><<<grid, 256, 0, s>>>(a, (float*)ws, pl.nb, pl.ppl); break;
+    case 7: dw_wgrad_kernel<7><<<grid, 256, 0, s>>>(a, (float*)ws, pl.nb, pl.ppl); break;
+    default: CAT_REQUIRE(false, "dwconv wgrad: kw %d unsupported", g->kw);
+  }
+  dw_wgrad_final_kernel<<<cdiv(g->Cin * g->kh * g->kw, 256), 256, 0, s>>>((const float*)ws, dw, g->Cin, g->xcs, g->kh * g->kw, pl.nb,
+                                                                            accumulate);
+  return cat::check_launch("dwconv2d_wgrad");
+}
+
+}  // extern "C"

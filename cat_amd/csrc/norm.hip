@@ -1,0 +1,307 @@
+// InstanceNorm2d / BatchNorm2d (training statistics) fused with the following activation, NHWC, gfx950.
+// HBM-bound: forward = 2 reads + 1 write of the activation, backward = 4 reads + 1 write.
+//   pass 1  per-(group, channel) shifted sums   sum(x - x0), sum((x - x0)^2)   -> deterministic partials in ws
+//   pass 2  finalize: mean / rstd (biased var, eps inside the sqrt), running stats, per-(group,channel) scale+shift
+//   pass 3  y = act(x * scale + shift), float4 per lane
+// Reduction layout: a workgroup walks pixels with (256 / quads) pixel-lanes x quads channel-quads, so every global
+// access is a float4 and a wave touches whole pixels (cs*4 contiguous bytes); cross-lane combine goes through LDS.
+#include "common.h"
+
+namespace {
+using cat::cdiv;
+
+struct NormPlan {
+  int G, Pg, nq, nz, zq, ppl, nb;
+  size_t part_off, scale_off, shift_off, c1_off, c2_off, bytes;
+};
+
+NormPlan plan(const cat_norm_t* g) {
+  NormPlan p;
+  p.G = g->mode == CAT_NORM_INSTANCE ? g->N : 1;
+  p.Pg = g->mode == CAT_NORM_INSTANCE ? g->HW : g->N * g->HW;
+  p.nq = g->cs / 4;
+  p.nz = cdiv(p.nq, 256);
+  p.zq = cdiv(p.nq, p.nz);  // quads per z-block (<= 256)
+  p.ppl = 256 / p.zq;
+  int nb = cdiv(2048, p.G * p.nz);
+  const int maxb = cdiv(p.Pg, p.ppl * 8);
+  if (nb > maxb) nb = maxb;
+  if (nb < 1) nb = 1;
+  p.nb = nb;
+  size_t off = 0;
+  p.part_off = off; off += (size_t)p.G * nb * 2 * g->cs;
+  p.scale_off = off; off += (size_t)p.G * g->cs;
+  p.shift_off = off; off += (size_t)p.G * g->cs;
+  p.c1_off = off; off += (size_t)p.G * g->cs;
+  p.c2_off = off; off += (size_t)p.G * g->cs;
+  p.bytes = off * sizeof(float);
+  return p;
+}
+
+// MODE 0: forward stats of x.  MODE 1: backward stats: sum(g), sum(g * xhat) with g = dy * act'(pre).
+template <int MODE>
+__global__ __launch_bounds__(256) void norm_stats_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                         float* __restrict__ part, int Pg, int C, int cs, int zq, int ppl, int nb,
+                                                         int act, float slope) {
+  __shared__ f4 red[2][256];
+  const int g = blockIdx.y, b = blockIdx.x, z = blockIdx.z;
+  const int tid = threadIdx.x;
+  const int cq_l = tid % zq, pl = tid / zq;
+  const int cq = z * zq + cq_l;
+  const bool active = pl < ppl && cq * 4 < cs;
+  const int per = (Pg + nb - 1) / nb;
+  const int pbeg = b * per, pend = min(Pg, pbeg + per);
+  const float* xg = x + (int64_t)g * Pg * cs;
+  f4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+  if (active) {
+    const int c = cq * 4;
+    if (MODE == 0) {
+      const f4 sh = *reinterpret_cast<const f4*>(xg + c);
+      for (int p = pbeg + pl; p < pend; p += ppl) {
+        const f4 v = *reinterpret_cast<const f4*>(xg + (int64_t)p * cs + c) - sh;
+        s0 += v;
+        s1 += v * v;
+      }
+    } else {
+      const float* dg = dy + (int64_t)g * Pg * cs;
+      f4 mu, rs, ga, be;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const bool cv = c + e < C;
+        mu[e] = cv ? mean[g * C + c + e] : 0.f;
+        rs[e] = cv ? rstd[g * C + c + e] : 0.f;
+        ga[e] = cv ? (gamma ? gamma[c + e] : 1.f) : 0.f;
+        be[e] = cv ? (beta ? beta[c + e] : 0.f) : 0.f;
+      }
+      for (int p = pbeg + pl; p < pend; p += ppl) {
+        const f4 xv = *reinterpret_cast<const f4*>(xg + (int64_t)p * cs + c);
+        f4 gv = *reinterpret_cast<const f4*>(dg + (int64_t)p * cs + c);
+        const f4 xh = (xv - mu) * rs;
+        if (act != CAT_ACT_NONE) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) gv[e] *= cat::act_grad_from_out(cat::apply_act(ga[e] * xh[e] + be[e], act, slope), act, slope);
+        }
+        s0 += gv;
+        s1 += gv * xh;
+      }
+    }
+  }
+  red[0][tid] = s0;
+  red[1][tid] = s1;
+  __syncthreads();
+  if (pl == 0 && cq * 4 < cs) {
+    for (int j = 1; j < ppl; ++j) {
+      s0 += red[0][j * zq + cq_l];
+      s1 += red[1][j * zq + cq_l];
+    }
+    float* dst = part + ((int64_t)(g * nb + b) * 2) * cs + cq * 4;
+    *reinterpret_cast<f4*>(dst) = s0;
+    *reinterpret_cast<f4*>(dst + cs) = s1;
+  }
+}
+
+__global__ __launch_bounds__(256) void norm_fwd_finalize_kernel(const float* __restrict__ x, const float* __restrict__ part,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                float* __restrict__ save_mean, float* __restrict__ save_rstd,
+                                                                float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                                float* __restrict__ scale, float* __restrict__ shift, int G, int Pg,
+                                                                int C, int cs, int nb, float eps, float momentum) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= G * cs) return;
+  const int g = idx / cs, c = idx - g * cs;
+  if (c >= C) {
+    scale[idx] = 0.f;
+    shift[idx] = 0.f;
+    return;
+  }
+  float s0 = 0.f, s1 = 0.f;
+  for (int b = 0; b < nb; ++b) {
+    const float* src = part + ((int64_t)(g * nb + b) * 2) * cs + c;
+    s0 += src[0];
+    s1 += src[cs];
+  }
+  const float inv = 1.f / (float)Pg;
+  const float d = s0 * inv;
+  const float mean = x[(int64_t)g * Pg * cs + c] + d;
+  float var = s1 * inv - d * d;
+  var = var > 0.f ? var : 0.f;
+  const float rstd = rsqrtf(var + eps);
+  save_mean[g * C + c] = mean;
+  save_rstd[g * C + c] = rstd;
+  if (running_mean) {  // batch norm only (G == 1)
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+    const float unb = Pg > 1 ? var * (float)Pg / (float)(Pg - 1) : var;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * unb;
+  }
+  const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
+  scale[idx] = ga * rstd;
+  shift[idx] = be - mean * ga * rstd;
+}
+
+// y = act(x * scale[g][c] + shift[g][c]); scale/shift hold zeros on padding channels.
+__global__ __launch_bounds__(256) void norm_apply_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, float* __restrict__ y, int64_t nquads, int nq,
+                                                         int64_t qpg, int cs, int act, float slope) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nquads; i += (int64_t)gridDim.x * 256) {
+    const int cq = (int)(i % nq);
+    const int g = (int)(i / qpg);
+    const f4 v = *reinterpret_cast<const f4*>(x + i * 4);
+    const f4 sc = *reinterpret_cast<const f4*>(scale + g * cs + cq * 4);
+    const f4 sh = *reinterpret_cast<const f4*>(shift + g * cs + cq * 4);
+    f4 o = v * sc + sh;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = cat::apply_act(o[e], act, slope);
+    *reinterpret_cast<f4*>(y + i * 4) = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void norm_bwd_finalize_kernel(const float* __restrict__ part, const float* __restrict__ gamma,
+                                                                const float* __restrict__ rstd, float* __restrict__ c1,
+                                                                float* __restrict__ c2, float* __restrict__ scale,
+                                                                float* __restrict__ dgamma, float* __restrict__ dbeta, int G, int Pg,
+                                                                int C, int cs, int nb, int accumulate) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= cs) return;
+  float tg = 0.f, tb = 0.f;
+  for (int g = 0; g < G; ++g) {
+    float s0 = 0.f, s1 = 0.f;
+    if (c < C) {
+      for (int b = 0; b < nb; ++b) {
+        const float* src = part + ((int64_t)(g * nb + b) * 2) * cs + c;
+        s0 += src[0];
+        s1 += src[cs];
+      }
+    }
+    tb += s0;
+    tg += s1;
+    const float inv = 1.f / (float)Pg;
+    c1[g * cs + c] = s0 * inv;
+    c2[g * cs + c] = s1 * inv;
+    scale[g * cs + c] = c < C ? (gamma ? gamma[c] : 1.f) * rstd[g * C + c] : 0.f;
+  }
+  if (c < C) {
+    if (dgamma) dgamma[c] = accumulate ? dgamma[c] + tg : tg;
+    if (dbeta) dbeta[c] = accumulate ? dbeta[c] + tb : tb;
+  }
+}
+
+// dx = gamma*rstd * (g - mean(g) - xhat * mean(g*xhat))
+__global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                             const float* __restrict__ c1, const float* __restrict__ c2,
+                                                             const float* __restrict__ scale, float* __restrict__ dx, int64_t nquads,
+                                                             int nq, int64_t qpg, int C, int cs, int act, float slope) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nquads; i += (int64_t)gridDim.x * 256) {
+    const int cq = (int)(i % nq);
+    const int g = (int)(i / qpg);
+    const int c = cq * 4;
+    const f4 xv = *reinterpret_cast<const f4*>(x + i * 4);
+    f4 gv = *reinterpret_cast<const f4*>(dy + i * 4);
+    const f4 m1 = *reinterpret_cast<const f4*>(c1 + g * cs + c);
+    const f4 m2 = *reinterpret_cast<const f4*>(c2 + g * cs + c);
+    const f4 sc = *reinterpret_cast<const f4*>(scale + g * cs + c);
+    f4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const bool cv = c + e < C;
+      const float mu = cv ? mean[g * C + c + e] : 0.f, rs = cv ? rstd[g * C + c + e] : 0.f;
+      const float xh = (xv[e] - mu) * rs;
+      float gg = gv[e];
+      if (act != CAT_ACT_NONE) {
+        const float ga = cv ? (gamma ? gamma[c + e] : 1.f) : 0.f, be = cv ? (beta ? beta[c + e] : 0.f) : 0.f;
+        gg *= cat::act_grad_from_out(cat::apply_act(ga * xh + be, act, slope), act, slope);
+      }
+      o[e] = sc[e] * (gg - m1[e] - xh * m2[e]);
+    }
+    *reinterpret_cast<f4*>(dx + i * 4) = o;
+  }
+}
+
+__global__ void bn_fold_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float eps, int C,
+                               float* scale, float* shift) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const float s = (gamma ? gamma[c] : 1.f) * rsqrtf(rv[c] + eps);
+  scale[c] = s;
+  shift[c] = (beta ? beta[c] : 0.f) - rm[c] * s;
+}
+
+__global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, float* __restrict__ y, int64_t nquads, int nq,
+                                                         int C, int act, float slope) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nquads; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % nq) * 4;
+    const f4 v = *reinterpret_cast<const f4*>(x + i * 4);
+    f4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = c + e < C ? cat::apply_act(v[e] * scale[c + e] + shift[c + e], act, slope) : 0.f;
+    *reinterpret_cast<f4*>(y + i * 4) = o;
+  }
+}
+
+int ew_grid(int64_t n) {
+  int64_t b = (n + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t cat_norm_ws_bytes(const cat_norm_t* g) { return plan(g).bytes; }
+
+int cat_norm_fwd(const cat_norm_t* g, const float* x, const float* gamma, const float* beta, float* y, float* save_mean,
+                 float* save_rstd, float* running_mean, float* running_var, void* ws, cat_stream_t stream) {
+  CAT_REQUIRE(g->cs % 4 == 0 && g->cs >= g->C && g->N > 0 && g->HW > 0, "norm: bad geometry");
+  CAT_REQUIRE(ws && save_mean && save_rstd, "norm fwd: workspace / save buffers required");
+  const NormPlan p = plan(g);
+  float* w = (float*)ws;
+  hipStream_t s = (hipStream_t)stream;
+  norm_stats_kernel<0><<<dim3(p.nb, p.G, p.nz), 256, 0, s>>>(x, nullptr, nullptr, nullptr, nullptr, nullptr, w + p.part_off, p.Pg,
+                                                              g->C, g->cs, p.zq, p.ppl, p.nb, 0, 0.f);
+  norm_fwd_finalize_kernel<<<cdiv(p.G * g->cs, 256), 256, 0, s>>>(x, w + p.part_off, gamma, beta, save_mean, save_rstd,
+                                                                   g->mode == CAT_NORM_BATCH ? running_mean : nullptr,
+                                                                   g->mode == CAT_NORM_BATCH ? running_var : nullptr, w + p.scale_off,
+                                                                   w + p.shift_off, p.G, p.Pg, g->C, g->cs, p.nb, g->eps, g->momentum);
+  const int64_t nquads = (int64_t)g->N * g->HW * p.nq;
+  norm_apply_kernel<<<ew_grid(nquads), 256, 0, s>>>(x, w + p.scale_off, w + p.shift_off, y, nquads, p.nq, (int64_t)p.Pg * p.nq, g->cs,
+                                                     g->act, g->slope);
+  return cat::check_launch("norm_fwd");
+}
+
+int cat_norm_bwd(const cat_norm_t* g, const float* x, const float* dy, const float* gamma, const float* beta, const float* save_mean,
+                 const float* save_rstd, float* dx, float* dgamma, float* dbeta, int accumulate, void* ws, cat_stream_t stream) {
+  CAT_REQUIRE(g->cs % 4 == 0 && g->cs >= g->C && g->N > 0 && g->HW > 0, "norm: bad geometry");
+  CAT_REQUIRE(ws, "norm bwd: workspace required");
+  const NormPlan p = plan(g);
+  float* w = (float*)ws;
+  hipStream_t s = (hipStream_t)stream;
+  norm_stats_kernel<1><<<dim3(p.nb, p.G, p.nz), 256, 0, s>>>(x, dy, gamma, beta, save_mean, save_rstd, w + p.part_off, p.Pg, g->C, g->cs,
+                                                              p.zq, p.ppl, p.nb, g->act, g->slope);
+  norm_bwd_finalize_kernel<<<cdiv(g->cs, 256), 256, 0, s>>>(w + p.part_off, gamma, save_rstd, w + p.c1_off, w + p.c2_off, w + p.scale_off,
+                                                             dgamma, dbeta, p.G, p.Pg, g->C, g->cs, p.nb, accumulate);
+  const int64_t nquads = (int64_t)g->N * g->HW * p.nq;
+  norm_bwd_apply_kernel<<<ew_grid(nquads), 256, 0, s>>>(x, dy, gamma, beta, save_mean, save_rstd, w + p.c1_off, w + p.c2_off,
+                                                         w + p.scale_off, dx, nquads, p.nq, (int64_t)p.Pg * p.nq, g->C, g->cs, g->act,
+                                                         g->slope);
+  return cat::check_launch("norm_bwd");
+}
+
+int cat_bn_fold(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps, int C,
+                float* scale, float* shift, cat_stream_t stream) {
+  bn_fold_kernel<<<cdiv(C, 256), 256, 0, (hipStream_t)stream>>>(gamma, beta, running_mean, running_var, eps, C, scale, shift);
+  return cat::check_launch("bn_fold");
+}
+
+int cat_affine_act_fwd(const float* x, const float* scale, const float* shift, float* y, int64_t M, int C, int cs, int act, float slope,
+                       cat_stream_t stream) {
+  CAT_REQUIRE(cs % 4 == 0 && cs >= C, "affine_act: bad channel stride");
+  const int64_t nquads = M * (cs / 4);
+  affine_act_kernel<<<ew_grid(nquads), 256, 0, (hipStream_t)stream>>>(x, scale, shift, y, nquads, cs / 4, C, act, slope);
+  return cat::check_launch("affine_act");
+}
+
+}  // extern "C"

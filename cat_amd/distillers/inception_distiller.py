@@ -1,0 +1,110 @@
+"""InceptionDistiller: the distillation step of distillers/inception_distiller.py:100-188 on the MI355X kernels.
+
+Data parallelism is process-per-GPU (cat_amd.parallel): each rank runs this class on its shard; the gradient
+buckets are all-reduced over RCCL and the loss seeds reproduce nn.DataParallel's semantics: recon / GAN
+terms are means over the global batch, the KA term is the SUM of per-shard KAs."""
+import torch
+from torch import nn
+
+from .. import ops
+from ..loss import KA
+from ..prune import model_profiling
+from .base_inception_distiller import BaseInceptionDistiller, LossValue
+
+
+class InceptionDistiller(BaseInceptionDistiller):
+    _FLAGS = [  # inception_distiller.py:39-69
+        ('--restore_pretrained_G_path', dict(type=str, default=None)),
+        ('--pretrained_netG', dict(type=str, default='inception_9blocks', choices=['inception_9blocks'])),
+        ('--pretrained_ngf', dict(type=int, default=64)),
+        ('--target_flops', dict(type=float, default=0)),
+        ('--prune_cin_lb', dict(type=int, default=0)),
+        ('--pretrained_student_G_path', dict(type=str, default=None)),
+        ('--prune_only', dict(action='store_true')),
+        ('--prune_continue', dict(action='store_true')),
+        ('--prune_logging_verbose', dict(action='store_true')),
+    ]
+
+    @staticmethod
+    def modify_commandline_options(parser, is_train):
+        assert is_train
+        parser = BaseInceptionDistiller.modify_commandline_options(parser, is_train)
+        for flag, kw in InceptionDistiller._FLAGS:
+            parser.add_argument(flag, **kw)
+        parser.set_defaults(norm='instance', dataset_mode='aligned', log_dir='logs/inception',
+                            teacher_netG='inception_9blocks', student_netG='inception_9blocks')
+        return parser
+
+    def __init__(self, opt):
+        assert opt.isTrain
+        super(InceptionDistiller, self).__init__(opt)
+        self.best_fid = 1e9
+        self.best_mIoU = -1e9
+        self.fids, self.mIoUs = [], []
+        h, w = getattr(opt, 'data_height', 256), getattr(opt, 'data_width', 256)
+        model_profiling(self.netG_teacher, h, w, channel=getattr(opt, 'data_channel', 3))
+        model_profiling(self.netG_student, h, w, channel=getattr(opt, 'data_channel', 3))
+
+    def forward(self, teacher_forward=True):
+        if teacher_forward:
+            with torch.no_grad():
+                self.Tfake_B = self.netG_teacher(self.real_A)
+        self.Sfake_B = self.netG_student(self.real_A)
+
+    def calc_distill_loss(self):
+        """sum_i -KA(Sact_i, Tact_i) (inception_distiller.py:106-157, 'ka' branch).  Returns the per-layer terms; the
+        weighted total is a LossValue (no torch arithmetic on the hot path)."""
+        if self.opt.distill_G_loss_type != 'ka':
+            raise NotImplementedError('distill_G_loss_type=%s: the accelerated path implements the KA loss the '
+                                      'distillation scripts use' % self.opt.distill_G_loss_type)
+        kas = []
+        for i, netA in enumerate(self.netAs):
+            assert isinstance(netA, nn.Conv2d)
+            n = self.mapping_layers[i]
+            key = n + str(self.device)
+            ka = KA(self.Sacts[key], self.Tacts[key])
+            setattr(self, 'loss_G_distill%d' % i, LossValue([(-1.0, ka)]))
+            kas.append(ka)
+        return kas
+
+    def backward_G(self, steps):
+        opt = self.opt
+        ws = self.dp.world_size if self.dp is not None else 1
+        sf_recon, sf_gan = ops.fanout(self.Sfake_B, 2)
+        if opt.dataset_mode == 'aligned':
+            recon = self.criterionRecon(sf_recon, self.real_B)
+            fake = ops.Concat2Fn.apply(self.real_A, sf_gan)
+        else:
+            recon = self.criterionRecon(sf_recon, self.Tfake_B)
+            fake = sf_gan
+        pred_fake = self.netD(fake)
+        gan = self.criterionGAN(pred_fake, True, for_discriminator=False)
+        self.loss_G_recon = LossValue([(opt.lambda_recon, recon)])
+        self.loss_G_gan = LossValue([(opt.lambda_gan, gan)])
+        terms, seeds = [gan, recon], [self.seed(opt.lambda_gan), self.seed(opt.lambda_recon)]
+        if opt.lambda_distill > 0:
+            kas = self.calc_distill_loss()
+            self.loss_G_distill = LossValue([(-opt.lambda_distill, k) for k in kas])
+            terms += kas
+            # DataParallel sums per-shard KA terms while every other term is a mean over the gathered batch: with
+            # gradient AVERAGING across ranks the KA seed therefore carries a factor world_size
+            seeds += [self.seed(-opt.lambda_distill * ws)] * len(kas)
+        else:
+            self.loss_G_distill = 0
+        self.loss_G = self.loss_G_gan + self.loss_G_recon + self.loss_G_distill
+        torch.autograd.backward(terms, seeds)
+
+    def optimize_parameters(self, steps):
+        self.forward()
+        self.set_requires_grad(self.netD, True)
+        self.optimizer_D.zero_grad()
+        self.backward_D()
+        if self.dp is not None:
+            self.dp.reduce(self.optimizer_D)
+        self.optimizer_D.step()
+        self.set_requires_grad(self.netD, False)
+        self.optimizer_G.zero_grad()
+        self.backward_G(steps)
+        if self.dp is not None:
+            self.dp.reduce(self.optimizer_G)
+        self.optimizer_G.step()

@@ -1,0 +1,190 @@
+"""Layer classes with the reference's names, constructor signatures, state_dict keys and default initialisation
+(they subclass the torch.nn classes CAT instantiates) whose forward runs the gfx950 kernels of libcat_hip.so.
+
+Fusion happens at call time, not by rewriting the module tree, so `shrink_model`-style surgery on
+`down_sampling[idx]` and forward hooks on any sub-module keep working exactly as in the reference:
+  ReflectionPad2d  -> returns a lazy `Padded` marker that the next conv folds into its im2col gather;
+  Conv / Norm      -> accept `fuse_act=` from `FusedSequential`, the activation module that follows is then called
+                      with `applied=True` (identity) so its hooks (e.g. 'down_sampling.9') still fire.
+"""
+import torch
+from torch import nn
+
+from . import _lib as L
+from . import ops
+
+
+class Padded:
+    """Activation + pending reflection padding (consumed by the next convolution)."""
+    __slots__ = ('x', 'pad', 'mode')
+
+    def __init__(self, x, pad, mode):
+        self.x, self.pad, self.mode = x, pad, mode
+
+
+def _act_code(m):
+    if m is None:
+        return L.ACT_NONE, 0.0
+    if isinstance(m, nn.LeakyReLU):
+        return L.ACT_LRELU, float(m.negative_slope)
+    if isinstance(m, nn.ReLU):
+        return L.ACT_RELU, 0.0
+    if isinstance(m, nn.Tanh):
+        return L.ACT_TANH, 0.0
+    raise NotImplementedError('activation %s has no fused kernel' % type(m).__name__)
+
+
+class _Act:
+    def forward(self, x, applied=False):
+        if applied:
+            return x
+        code, slope = _act_code(self)
+        return ops.ActFn.apply(x, code, slope)
+
+
+class ReLU(_Act, nn.ReLU):
+    pass
+
+
+class LeakyReLU(_Act, nn.LeakyReLU):
+    pass
+
+
+class Tanh(_Act, nn.Tanh):
+    pass
+
+
+_ACTS = (ReLU, LeakyReLU, Tanh)
+
+
+class Identity(nn.Module):
+    def forward(self, x):
+        return x
+
+
+class Dropout(nn.Dropout):
+    """The distillation scripts all run with dropout_rate 0; a non-zero rate is not on the path."""
+
+    def forward(self, x):
+        if self.p != 0 and self.training:
+            raise NotImplementedError('dropout with p > 0 is outside the accelerated hot path')
+        return x
+
+
+class ReflectionPad2d(nn.ReflectionPad2d):
+    def forward(self, x):
+        p = self.padding[0]
+        if any(q != p for q in self.padding):
+            raise NotImplementedError('only symmetric reflection padding is supported')
+        if isinstance(x, Padded):
+            raise NotImplementedError('stacked paddings')
+        return Padded(x, p, L.PAD_REFLECT) if p > 0 else x
+
+
+class ZeroPad2d(nn.ConstantPad2d):
+    def __init__(self, padding, value=0.0):
+        super().__init__(padding, value)
+
+    def forward(self, x):
+        p = self.padding[0]
+        if any(q != p for q in self.padding) or self.value != 0:
+            raise NotImplementedError('only symmetric zero padding is supported')
+        return Padded(x, p, L.PAD_ZERO) if p > 0 else x
+
+
+def _to_channels_last_(module):
+    w = module.weight
+    if w.dim() == 4 and w.shape[1] > 1 and not w.permute(0, 2, 3, 1).is_contiguous():
+        w.data = w.data.contiguous(memory_format=torch.channels_last)
+
+
+class Conv2d(nn.Conv2d):
+    """nn.Conv2d (dense or depthwise).  Weight storage is channels_last ([O][kh][kw][I]); state_dict values are
+    unchanged (logical OIHW)."""
+
+    def forward(self, x, fuse_act=None):
+        pad, mode = self.padding[0], L.PAD_ZERO
+        if isinstance(x, Padded):
+            if pad != 0:
+                raise NotImplementedError('explicit padding in front of a padded conv')
+            x, pad, mode = x.x, x.pad, x.mode
+        if self.padding[0] != self.padding[1] or self.stride[0] != self.stride[1] or self.dilation != (1, 1):
+            raise NotImplementedError('conv2d: only square stride/padding and dilation 1')
+        if self.padding_mode != 'zeros':
+            raise NotImplementedError('conv2d: use ReflectionPad2d for reflect padding (as the reference does)')
+        act, slope = _act_code(fuse_act)
+        if self.groups == 1:
+            _to_channels_last_(self)
+            return ops.Conv2dFn.apply(x, self.weight, self.bias, self.stride[0], pad, mode, act, slope)
+        if self.groups == self.in_channels == self.out_channels and self.stride[0] == 1:
+            y = ops.DwConv2dFn.apply(x, self.weight, self.bias, pad, mode)
+            return ops.ActFn.apply(y, act, slope) if act != L.ACT_NONE else y
+        raise NotImplementedError('conv2d: groups must be 1 or == channels (depthwise, stride 1)')
+
+
+class ConvTranspose2d(nn.ConvTranspose2d):
+    def forward(self, x, fuse_act=None):
+        if isinstance(x, Padded):
+            raise NotImplementedError('padding in front of a transposed conv')
+        if self.groups != 1 or self.dilation != (1, 1) or self.stride[0] != self.stride[1] or self.padding[0] != self.padding[1]:
+            raise NotImplementedError('conv_transpose2d: groups 1, dilation 1, square geometry only')
+        _to_channels_last_(self)
+        y = ops.ConvTranspose2dFn.apply(x, self.weight, self.bias, self.stride[0], self.padding[0], self.output_padding[0])
+        if fuse_act is not None:
+            act, slope = _act_code(fuse_act)
+            y = ops.ActFn.apply(y, act, slope)
+        return y
+
+
+class _NormMixin:
+    def _run(self, x, mode, use_batch_stats, fuse_act):
+        if isinstance(x, Padded):
+            raise NotImplementedError('padding in front of a norm layer')
+        act, slope = _act_code(fuse_act)
+        if use_batch_stats:
+            rm = rv = None
+            if mode == L.NORM_BATCH and self.training and self.track_running_stats:
+                rm, rv = self.running_mean, self.running_var
+                if self.momentum is None:
+                    raise NotImplementedError('cumulative-average BatchNorm (momentum=None)')
+                self.num_batches_tracked.add_(1)
+            return ops.NormActFn.apply(x, self.weight, self.bias, rm, rv, mode, float(self.eps),
+                                       float(self.momentum if self.momentum is not None else 0.0), act, slope)
+        scale, shift = ops.bn_fold(self.weight, self.bias, self.running_mean, self.running_var, float(self.eps))
+        return ops.affine_act(x, scale, shift, act, slope)
+
+
+class BatchNorm2d(_NormMixin, nn.BatchNorm2d):
+    def forward(self, x, fuse_act=None):
+        use_batch = self.training or not self.track_running_stats
+        return self._run(x, L.NORM_BATCH, use_batch, fuse_act)
+
+
+class InstanceNorm2d(_NormMixin, nn.InstanceNorm2d):
+    def forward(self, x, fuse_act=None):
+        if self.track_running_stats:
+            raise NotImplementedError('InstanceNorm2d(track_running_stats=True) is not used by the distillation scripts')
+        return self._run(x, L.NORM_INSTANCE, True, fuse_act)
+
+
+_FUSABLE = (Conv2d, ConvTranspose2d, BatchNorm2d, InstanceNorm2d)
+_NORMS = (BatchNorm2d, InstanceNorm2d)
+
+
+class FusedSequential(nn.Sequential):
+    """nn.Sequential that hands the activation following a conv / norm to that layer's kernel epilogue."""
+
+    def forward(self, x):
+        mods = list(self)
+        i, n = 0, len(mods)
+        while i < n:
+            m = mods[i]
+            nxt = mods[i + 1] if i + 1 < n else None
+            if isinstance(m, _FUSABLE) and isinstance(nxt, _ACTS):
+                x = m(x, fuse_act=nxt)
+                x = nxt(x, applied=True)
+                i += 2
+            else:
+                x = m(x)
+                i += 1
+        return x

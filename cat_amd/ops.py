@@ -1,0 +1,569 @@
+"""torch.autograd.Function wrappers over the C-ABI kernels (include/cat_hip.h).
+
+Tensors on the hot path are "NHWC activations": logical shape [N, C, H, W] (what the reference sees), physical
+layout [N][H][W][cs] with cs = round_up(C, 4) floats per pixel and zero padding channels.  PyTorch only provides
+device memory, the stream and the autograd tape; every arithmetic op below is a HIP kernel of libcat_hip.so and
+raises if the library is missing (no eager / CPU fallback)."""
+import ctypes as C
+import warnings
+
+import torch
+
+from . import _lib as L
+from ._lib import ConvGeom, NormGeom
+
+STATS = {'conform_copies': 0}   # non-native layout fix-ups; must stay 0 on the distillation hot path
+
+
+# ---------------------------------------------------------------------------------------------- layout helpers
+def cs_for(c):
+    return (c + 3) // 4 * 4
+
+
+def empty_act(n, c, h, w, device, cs=None):
+    cs = cs or cs_for(c)
+    buf = torch.empty((n, h, w, cs), device=device, dtype=torch.float32)
+    return buf[..., :c].permute(0, 3, 1, 2)
+
+
+def act_cs(t):
+    n, c, h, w = t.shape
+    if w > 1:
+        return t.stride(3)
+    if h > 1:
+        return t.stride(2)
+    return t.stride(0) if n > 1 else cs_for(c)
+
+
+def is_act(t):
+    if t.dim() != 4 or t.dtype != torch.float32:
+        return False
+    n, c, h, w = t.shape
+    cs = act_cs(t)
+    if cs % 4 or cs < c or t.data_ptr() % 16:
+        return False
+    ok = (c == 1 or t.stride(1) == 1)
+    ok = ok and (w == 1 or t.stride(3) == cs) and (h == 1 or t.stride(2) == w * cs) and (n == 1 or t.stride(0) == h * w * cs)
+    return ok
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _require_cuda(t):
+    if not t.is_cuda:
+        raise RuntimeError('cat_amd ops run on the GPU only (HIP kernels, no CPU fallback); got a %s tensor' % t.device)
+
+
+_WS = {}
+
+
+def workspace(nbytes, device):
+    """Per-(device, stream) scratch reused by consecutive kernels of one stream."""
+    key = (device, torch.cuda.current_stream().cuda_stream)
+    buf = _WS.get(key)
+    if buf is None or buf.numel() * 4 < nbytes:
+        buf = torch.empty((max(nbytes, 1 << 20) + 3) // 4, device=device, dtype=torch.float32)
+        _WS[key] = buf
+    return buf
+
+
+def to_nhwc(x):
+    """NCHW-contiguous (reference layout) -> NHWC activation, through cat_nchw_to_nhwc."""
+    _require_cuda(x)
+    if is_act(x):
+        return x
+    x = x.contiguous()
+    n, c, h, w = x.shape
+    y = empty_act(n, c, h, w, x.device)
+    L.call('cat_nchw_to_nhwc', _p(x), _p(y), n, c, h, w, act_cs(y), _stream())
+    return y
+
+
+def to_nchw(x):
+    """NHWC activation -> NCHW-contiguous tensor."""
+    _require_cuda(x)
+    if not is_act(x):
+        return x.contiguous()
+    n, c, h, w = x.shape
+    y = torch.empty((n, c, h, w), device=x.device, dtype=torch.float32)
+    L.call('cat_nhwc_to_nchw', _p(x), _p(y), n, c, h, w, act_cs(x), _stream())
+    return y
+
+
+def conform(t):
+    """Make `t` an NHWC activation.  Gradients produced by our own kernels already are; anything else (e.g. a
+    gradient torch itself accumulated) is re-laid-out and counted."""
+    if is_act(t):
+        return t
+    STATS['conform_copies'] += 1
+    if t.is_contiguous():
+        return to_nhwc(t)
+    n, c, h, w = t.shape
+    y = empty_act(n, c, h, w, t.device)
+    full = torch.as_strided(y, (n, act_cs(y), h, w), y.stride())
+    full.zero_()
+    y.copy_(t)
+    return y
+
+
+def weight_cl(w):
+    """Conv weights must be physically [O][kh][kw][I] (torch channels_last)."""
+    if w.dim() == 4 and w.permute(0, 2, 3, 1).is_contiguous():
+        return w
+    return w.contiguous(memory_format=torch.channels_last)
+
+
+def _conv_geom(n, h, w, cin, xcs, ho, wo, cout, ycs, kh, kw, stride, pad, pad_mode, act=0, slope=0.0, ycw=0):
+    return ConvGeom(n, h, w, cin, xcs, ho, wo, cout, ycs, kh, kw, stride, pad, pad_mode, act, slope, ycw)
+
+
+def _grad_target(param):
+    """FusedAdam registers a flat gradient buffer view on its parameters: wgrad kernels then write (or
+    accumulate) straight into it and autograd sees no weight gradient at all."""
+    return getattr(param, '_cat_grad_view', None)
+
+
+def _write_param_grad(param, kernel):
+    """kernel(dst_tensor, accumulate_flag).  Returns the tensor to hand back to autograd (None if direct)."""
+    tgt = _grad_target(param)
+    if tgt is not None:
+        st = param._cat_grad_state
+        kernel(tgt, 0 if st['fresh'] else 1)
+        st['fresh'] = False
+        return None
+    if param.dim() == 4 and param.shape[1] > 1:
+        g = torch.empty(param.shape, device=param.device, dtype=param.dtype, memory_format=torch.channels_last)
+    else:
+        g = torch.empty(param.shape, device=param.device, dtype=param.dtype)
+    kernel(g, 0)
+    return g
+
+
+def _act_bwd(y, dy, act, slope):
+    n, c, h, w = y.shape
+    dz = empty_act(n, c, h, w, y.device, act_cs(y))
+    L.call('cat_act_bwd', _p(y), _p(dy), _p(dz), n * h * w * act_cs(y), act, slope, _stream())
+    return dz
+
+
+def _nchw(t):
+    n, c, h, w = t.shape
+    return n, c, h, w
+
+
+# ---------------------------------------------------------------------------------------------- convolutions
+class Conv2dFn(torch.autograd.Function):
+    """nn.Conv2d (+ preceding ReflectionPad2d, + following pointwise activation)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad, pad_mode, act, slope):
+        _require_cuda(x)
+        x = conform(x)
+        wcl = weight_cl(weight)
+        n, cin, h, w = x.shape
+        cout, cin_w, kh, kw = weight.shape
+        if cin_w != cin:
+            raise RuntimeError(f'conv2d: input has {cin} channels, weight expects {cin_w}')
+        ho = (h + 2 * pad - kh) // stride + 1
+        wo = (w + 2 * pad - kw) // stride + 1
+        y = empty_act(n, cout, ho, wo, x.device)
+        g = _conv_geom(n, h, w, cin, act_cs(x), ho, wo, cout, act_cs(y), kh, kw, stride, pad, pad_mode, act, slope, act_cs(y))
+        L.call('cat_conv2d_fwd', C.byref(g), _p(x), _p(wcl), _p(bias), _p(y), _stream())
+        ctx.geom = (n, h, w, cin, act_cs(x), ho, wo, cout, act_cs(y), kh, kw, stride, pad, pad_mode)
+        ctx.act, ctx.slope = act, slope
+        ctx.weight, ctx.bias = weight, bias
+        ctx.save_for_backward(x, wcl, y if act != L.ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wcl, y = ctx.saved_tensors
+        n, h, w, cin, xcs, ho, wo, cout, ycs, kh, kw, stride, pad, pad_mode = ctx.geom
+        dy = conform(dy)
+        if ctx.act != L.ACT_NONE:
+            dy = _act_bwd(y, dy, ctx.act, ctx.slope)
+        g = _conv_geom(n, h, w, cin, xcs, ho, wo, cout, act_cs(dy), kh, kw, stride, pad, pad_mode)
+        st = _stream()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            if pad_mode == L.PAD_REFLECT and pad > 0:
+                dxp = empty_act(n, cin, h + 2 * pad, w + 2 * pad, x.device)
+                L.call('cat_conv2d_dgrad', C.byref(g), _p(dy), _p(wcl), None, _p(dxp), act_cs(dxp), act_cs(dxp), st)
+                dx = empty_act(n, cin, h, w, x.device)
+                L.call('cat_reflect_pad_bwd', _p(dxp), _p(dx), n, h, w, cin, act_cs(dx), pad, st)
+            else:
+                dx = empty_act(n, cin, h, w, x.device)
+                L.call('cat_conv2d_dgrad', C.byref(g), _p(dy), _p(wcl), None, _p(dx), act_cs(dx), act_cs(dx), st)
+        if ctx.needs_input_grad[1]:
+            ws = workspace(L.query('cat_conv2d_wgrad_ws_bytes', C.byref(g)), x.device)
+
+            def k(dst, acc):
+                L.call('cat_conv2d_wgrad', C.byref(g), _p(x), _p(dy), _p(dst), acc, _p(ws), st)
+            dw = _write_param_grad(ctx.weight, lambda dst, acc: k(_as_cl(dst), acc))
+        if ctx.bias is not None and ctx.needs_input_grad[2]:
+            m = n * ho * wo
+            ws = workspace(L.query('cat_channel_sum_ws_bytes', m, act_cs(dy)), x.device)
+            db = _write_param_grad(ctx.bias, lambda dst, acc: L.call('cat_channel_sum', _p(dy), m, cout, act_cs(dy), _p(dst), acc,
+                                                                     _p(ws), st))
+        return dx, dw, db, None, None, None, None, None
+
+
+def _as_cl(t):
+    if t.dim() == 4 and not t.permute(0, 2, 3, 1).is_contiguous():
+        raise RuntimeError('conv weight gradient buffer must be channels_last (physical [O][kh][kw][I])')
+    return t
+
+
+class ConvTranspose2dFn(torch.autograd.Function):
+    """nn.ConvTranspose2d: forward is the dgrad kernel of the equivalent strided conv
+    (conv input = our output), backward-data is that conv's forward, backward-weights its wgrad."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad, output_padding):
+        _require_cuda(x)
+        x = conform(x)
+        wcl = weight_cl(weight)
+        n, cin_t, hi, wi = x.shape
+        cin_w, cout_t, kh, kw = weight.shape
+        if cin_w != cin_t:
+            raise RuntimeError(f'conv_transpose2d: input has {cin_t} channels, weight expects {cin_w}')
+        ho = (hi - 1) * stride - 2 * pad + kh + output_padding
+        wo = (wi - 1) * stride - 2 * pad + kw + output_padding
+        y = empty_act(n, cout_t, ho, wo, x.device)
+        # equivalent conv: input (ho, wo, cout_t) -> output (hi, wi, cin_t)
+        g = _conv_geom(n, ho, wo, cout_t, act_cs(y), hi, wi, cin_t, act_cs(x), kh, kw, stride, pad, L.PAD_ZERO)
+        L.call('cat_conv2d_dgrad', C.byref(g), _p(x), _p(wcl), _p(bias), _p(y), act_cs(y), act_cs(y), _stream())
+        ctx.geom = (n, ho, wo, cout_t, act_cs(y), hi, wi, cin_t, act_cs(x), kh, kw, stride, pad)
+        ctx.weight, ctx.bias = weight, bias
+        ctx.save_for_backward(x, wcl)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wcl = ctx.saved_tensors
+        n, ho, wo, cout_t, ycs, hi, wi, cin_t, xcs, kh, kw, stride, pad = ctx.geom
+        dy = conform(dy)
+        st = _stream()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = empty_act(n, cin_t, hi, wi, x.device)
+            g = _conv_geom(n, ho, wo, cout_t, act_cs(dy), hi, wi, cin_t, act_cs(dx), kh, kw, stride, pad, L.PAD_ZERO, 0, 0.0, act_cs(dx))
+            L.call('cat_conv2d_fwd', C.byref(g), _p(dy), _p(wcl), None, _p(dx), st)
+        if ctx.needs_input_grad[1]:
+            g = _conv_geom(n, ho, wo, cout_t, act_cs(dy), hi, wi, cin_t, xcs, kh, kw, stride, pad, L.PAD_ZERO)
+            ws = workspace(L.query('cat_conv2d_wgrad_ws_bytes', C.byref(g)), x.device)
+            dw = _write_param_grad(ctx.weight, lambda dst, acc: L.call('cat_conv2d_wgrad', C.byref(g), _p(dy), _p(x), _p(_as_cl(dst)), acc,
+                                                                       _p(ws), st))
+        if ctx.bias is not None and ctx.needs_input_grad[2]:
+            m = n * ho * wo
+            ws = workspace(L.query('cat_channel_sum_ws_bytes', m, act_cs(dy)), x.device)
+            db = _write_param_grad(ctx.bias, lambda dst, acc: L.call('cat_channel_sum', _p(dy), m, cout_t, act_cs(dy), _p(dst), acc,
+                                                                     _p(ws), st))
+        return dx, dw, db, None, None, None
+
+
+class DwConv2dFn(torch.autograd.Function):
+    """Depthwise nn.Conv2d(groups=C), stride 1 (+ preceding ReflectionPad2d)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, pad, pad_mode):
+        _require_cuda(x)
+        x = conform(x)
+        n, c, h, w = x.shape
+        cw, one, kh, kw = weight.shape
+        if cw != c or one != 1:
+            raise RuntimeError('depthwise conv2d: weight must be [C,1,kh,kw] with C == input channels')
+        wc = weight.contiguous()
+        ho, wo = h + 2 * pad - kh + 1, w + 2 * pad - kw + 1
+        y = empty_act(n, c, ho, wo, x.device)
+        g = _conv_geom(n, h, w, c, act_cs(x), ho, wo, c, act_cs(y), kh, kw, 1, pad, pad_mode)
+        L.call('cat_dwconv2d_fwd', C.byref(g), _p(x), _p(wc), _p(bias), _p(y), _stream())
+        ctx.geom = (n, h, w, c, act_cs(x), ho, wo, kh, kw, pad, pad_mode)
+        ctx.weight, ctx.bias = weight, bias
+        ctx.save_for_backward(x, wc)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wc = ctx.saved_tensors
+        n, h, w, c, xcs, ho, wo, kh, kw, pad, pad_mode = ctx.geom
+        dy = conform(dy)
+        g = _conv_geom(n, h, w, c, xcs, ho, wo, c, act_cs(dy), kh, kw, 1, pad, pad_mode)
+        st = _stream()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            if pad_mode == L.PAD_REFLECT and pad > 0:
+                dxp = empty_act(n, c, h + 2 * pad, w + 2 * pad, x.device)
+                L.call('cat_dwconv2d_dgrad', C.byref(g), _p(dy), _p(wc), _p(dxp), act_cs(dxp), st)
+                dx = empty_act(n, c, h, w, x.device)
+                L.call('cat_reflect_pad_bwd', _p(dxp), _p(dx), n, h, w, c, act_cs(dx), pad, st)
+            else:
+                dx = empty_act(n, c, h, w, x.device)
+                L.call('cat_dwconv2d_dgrad', C.byref(g), _p(dy), _p(wc), _p(dx), act_cs(dx), st)
+        if ctx.needs_input_grad[1]:
+            ws = workspace(L.query('cat_dwconv2d_wgrad_ws_bytes', C.byref(g)), x.device)
+            dw = _write_param_grad(ctx.weight, lambda dst, acc: L.call('cat_dwconv2d_wgrad', C.byref(g), _p(x), _p(dy), _p(dst), acc,
+                                                                       _p(ws), st))
+        if ctx.bias is not None and ctx.needs_input_grad[2]:
+            m = n * ho * wo
+            ws = workspace(L.query('cat_channel_sum_ws_bytes', m, act_cs(dy)), x.device)
+            db = _write_param_grad(ctx.bias, lambda dst, acc: L.call('cat_channel_sum', _p(dy), m, c, act_cs(dy), _p(dst), acc, _p(ws),
+                                                                     st))
+        return dx, dw, db, None, None
+
+
+# ---------------------------------------------------------------------------------------------- normalisation
+class NormActFn(torch.autograd.Function):
+    """InstanceNorm2d / BatchNorm2d with batch statistics, fused with the activation behind it."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, mode, eps, momentum, act, slope):
+        _require_cuda(x)
+        x = conform(x)
+        n, c, h, w = x.shape
+        cs = act_cs(x)
+        y = empty_act(n, c, h, w, x.device, cs)
+        g = NormGeom(n, h * w, c, cs, mode, eps, momentum, act, slope)
+        groups = n if mode == L.NORM_INSTANCE else 1
+        mean = torch.empty((groups, c), device=x.device, dtype=torch.float32)
+        rstd = torch.empty((groups, c), device=x.device, dtype=torch.float32)
+        ws = workspace(L.query('cat_norm_ws_bytes', C.byref(g)), x.device)
+        L.call('cat_norm_fwd', C.byref(g), _p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), _p(running_mean), _p(running_var),
+               _p(ws), _stream())
+        ctx.geom = (n, h * w, c, cs, mode, eps, momentum, act, slope)
+        ctx.gamma, ctx.beta = gamma, beta
+        ctx.save_for_backward(x, mean, rstd, gamma, beta)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd, gamma, beta = ctx.saved_tensors
+        n, c, h, w = x.shape
+        dy = conform(dy)
+        if act_cs(dy) != act_cs(x):
+            raise RuntimeError('norm backward: gradient pixel stride differs from the input')
+        g = NormGeom(*ctx.geom)
+        dx = empty_act(n, c, h, w, x.device, act_cs(x))
+        ws = workspace(L.query('cat_norm_ws_bytes', C.byref(g)), x.device)
+        st = _stream()
+        need_g = gamma is not None and ctx.needs_input_grad[1]
+        need_b = beta is not None and ctx.needs_input_grad[2]
+        dgamma = dbeta = None
+        tg = _grad_target(ctx.gamma) if need_g else None
+        tb = _grad_target(ctx.beta) if need_b else None
+        direct = need_g and need_b and tg is not None and tb is not None
+        if direct:
+            sg, sb = ctx.gamma._cat_grad_state, ctx.beta._cat_grad_state
+            if sg['fresh'] != sb['fresh']:
+                raise RuntimeError('norm backward: gamma / beta gradient buffers out of sync')
+            acc = 0 if sg['fresh'] else 1
+            L.call('cat_norm_bwd', C.byref(g), _p(x), _p(dy), _p(gamma), _p(beta), _p(mean), _p(rstd), _p(dx), _p(tg), _p(tb), acc,
+                   _p(ws), st)
+            sg['fresh'] = sb['fresh'] = False
+        else:
+            dgamma = torch.empty_like(gamma) if need_g else None
+            dbeta = torch.empty_like(beta) if need_b else None
+            L.call('cat_norm_bwd', C.byref(g), _p(x), _p(dy), _p(gamma), _p(beta), _p(mean), _p(rstd), _p(dx), _p(dgamma), _p(dbeta), 0,
+                   _p(ws), st)
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None
+
+
+def affine_act(x, scale, shift, act, slope):
+    """Inference-mode norm (running statistics folded into scale/shift): no autograd (frozen teacher only)."""
+    _require_cuda(x)
+    x = conform(x)
+    if x.requires_grad and torch.is_grad_enabled():
+        raise NotImplementedError('eval-mode BatchNorm is only implemented for the frozen (no-grad) teacher')
+    n, c, h, w = x.shape
+    y = empty_act(n, c, h, w, x.device, act_cs(x))
+    L.call('cat_affine_act_fwd', _p(x), _p(scale), _p(shift), _p(y), n * h * w, c, act_cs(x), act, slope, _stream())
+    return y
+
+
+def bn_fold(gamma, beta, running_mean, running_var, eps):
+    c = running_mean.numel()
+    scale = torch.empty(c, device=running_mean.device, dtype=torch.float32)
+    shift = torch.empty_like(scale)
+    L.call('cat_bn_fold', _p(gamma), _p(beta), _p(running_mean), _p(running_var), eps, c, _p(scale), _p(shift), _stream())
+    return scale, shift
+
+
+# ---------------------------------------------------------------------------------------------- pointwise
+class ActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, act, slope):
+        _require_cuda(x)
+        x = conform(x)
+        n, c, h, w = x.shape
+        y = empty_act(n, c, h, w, x.device, act_cs(x))
+        L.call('cat_act_fwd', _p(x), _p(y), n * h * w * act_cs(x), act, slope, _stream())
+        ctx.act, ctx.slope = act, slope
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        return _act_bwd(y, conform(dy), ctx.act, ctx.slope), None, None
+
+
+class AddNFn(torch.autograd.Function):
+    """sum of k same-shaped activations (branch sum + residual of InvertedResidualChannels)."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        xs = [conform(x) for x in xs]
+        _require_cuda(xs[0])
+        n, c, h, w = xs[0].shape
+        cs = act_cs(xs[0])
+        for x in xs:
+            if x.shape != xs[0].shape or act_cs(x) != cs:
+                raise RuntimeError('add_n: operands must share shape and pixel stride')
+        y = empty_act(n, c, h, w, xs[0].device, cs)
+        arr = (C.c_void_p * len(xs))(*[x.data_ptr() for x in xs])
+        L.call('cat_add_n', arr, len(xs), _p(y), n * h * w * cs, _stream())
+        ctx.k = len(xs)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = conform(dy)
+        return tuple(dy for _ in range(ctx.k))
+
+
+class FanoutFn(torch.autograd.Function):
+    """k aliases of one activation; the backward sums the k gradients with one add_n kernel, so autograd never
+    accumulates fan-out gradients with its own (layout-breaking) adds."""
+
+    @staticmethod
+    def forward(ctx, x, k):
+        ctx.k = k
+        return tuple(x.view_as(x) for _ in range(k))
+
+    @staticmethod
+    def backward(ctx, *dys):
+        dys = [conform(d) for d in dys if d is not None]
+        if not dys:
+            return None, None
+        if len(dys) == 1:
+            return dys[0], None
+        n, c, h, w = dys[0].shape
+        cs = act_cs(dys[0])
+        out = empty_act(n, c, h, w, dys[0].device, cs)
+        srcs, rest = dys[:8], dys[8:]
+        while True:                          # add_n takes up to 8 sources; dst may alias src[0]
+            arr = (C.c_void_p * len(srcs))(*[d.data_ptr() for d in srcs])
+            L.call('cat_add_n', arr, len(srcs), _p(out), n * h * w * cs, _stream())
+            if not rest:
+                break
+            srcs, rest = [out] + rest[:7], rest[7:]
+        return out, None
+
+
+def fanout(x, k):
+    if k == 1:
+        return (x,)
+    return FanoutFn.apply(x, k)
+
+
+class Concat2Fn(torch.autograd.Function):
+    """torch.cat((a, b), 1) for NHWC activations."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        _require_cuda(a)
+        a, b = conform(a), conform(b)
+        n, ca, h, w = a.shape
+        cb = b.shape[1]
+        y = empty_act(n, ca + cb, h, w, a.device)
+        L.call('cat_concat2', _p(a), ca, act_cs(a), _p(b), cb, act_cs(b), _p(y), act_cs(y), n * h * w, _stream())
+        ctx.dims = (n, ca, cb, h, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        n, ca, cb, h, w = ctx.dims
+        dy = conform(dy)
+        da = db = None
+        if ctx.needs_input_grad[0]:
+            da = empty_act(n, ca, h, w, dy.device)
+            L.call('cat_slice_channels', _p(dy), act_cs(dy), 0, ca, _p(da), act_cs(da), n * h * w, _stream())
+        if ctx.needs_input_grad[1]:
+            db = empty_act(n, cb, h, w, dy.device)
+            L.call('cat_slice_channels', _p(dy), act_cs(dy), ca, cb, _p(db), act_cs(db), n * h * w, _stream())
+        return da, db
+
+
+# ---------------------------------------------------------------------------------------------- losses
+class KAFn(torch.autograd.Function):
+    """Kernel alignment between two activation stacks (utils/common.py:38-46); gradient flows to X only."""
+
+    @staticmethod
+    def forward(ctx, x, y):
+        _require_cuda(x)
+        x, y = conform(x), conform(y)
+        n = x.shape[0]
+        if y.shape[0] != n:
+            raise AssertionError(f'X_ and Y_ must have the same shape on dim 0, but got {n} for X_ and {y.shape[0]} for Y_.')
+        dx_len = x.shape[2] * x.shape[3] * act_cs(x)
+        dy_len = y.shape[2] * y.shape[3] * act_cs(y)
+        ws = torch.empty(L.query('cat_ka_ws_bytes', n) // 4, device=x.device, dtype=torch.float32)
+        out = torch.empty((), device=x.device, dtype=torch.float32)
+        L.call('cat_ka_fwd', _p(x), dx_len, _p(y), dy_len, n, _p(out), _p(ws), _stream())
+        ctx.save_for_backward(x, ws)
+        ctx.dx_len = dx_len
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, ws = ctx.saved_tensors
+        n, c, h, w = x.shape
+        dx = empty_act(n, c, h, w, x.device, act_cs(x))
+        gout = gout.contiguous()
+        L.call('cat_ka_bwd', _p(x), ctx.dx_len, n, _p(gout), _p(ws), _p(dx), _stream())
+        return dx, None
+
+
+class LossFn(torch.autograd.Function):
+    """mean-reduced scalar losses (L1 / MSE / lsgan / hinge); see cat_loss_fwd in include/cat_hip.h."""
+
+    @staticmethod
+    def forward(ctx, a, b, kind, target):
+        _require_cuda(a)
+        a = conform(a)
+        n, c, h, w = a.shape
+        if b is not None:
+            b = conform(b)
+            if b.shape != a.shape or act_cs(b) != act_cs(a):
+                raise RuntimeError('loss: operands must share shape and pixel stride')
+        out = torch.empty((), device=a.device, dtype=torch.float32)
+        ws = workspace(L.query('cat_loss_ws_bytes', n * h * w), a.device)
+        L.call('cat_loss_fwd', kind, _p(a), _p(b), float(target), n * h * w, c, act_cs(a), _p(out), _p(ws), _stream())
+        ctx.kind, ctx.target = kind, float(target)
+        ctx.save_for_backward(a, b)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        a, b = ctx.saved_tensors
+        n, c, h, w = a.shape
+        da = empty_act(n, c, h, w, a.device, act_cs(a))
+        gout = gout.contiguous()
+        L.call('cat_loss_bwd', ctx.kind, _p(a), _p(b), ctx.target, n * h * w, c, act_cs(a), _p(gout), 1.0, _p(da), _stream())
+        return da, None, None, None
+
+
+def ka(x, y):
+    return KAFn.apply(x, y)
+
+
+def fill_(t, value):
+    """In-place fill of a dense fp32 buffer with the library's kernel."""
+    L.call('cat_fill', _p(t), t.numel(), float(value), _stream())
+    return t

@@ -1,0 +1,152 @@
+/* cat_hip.h — C-ABI of libcat_hip.so: the MI355X (gfx950) kernels behind CAT's generator-distillation step.
+ *
+ * snap-research/CAT has no native code: every "kernel" on its hot path is a stock torch.nn op.
+ * Each entry point below therefore replaces the torch op(s) a reference call site issues; the reference
+ * file:line that issues them is cited per function.  The host binding is ctypes (cat_amd/_lib.py);
+ * INTEGRATION.md shows the stub a CAT maintainer would add.
+ *
+ * Conventions
+ *   - All tensors are fp32, resident in HBM, NHWC ("channels last").  An activation is described by
+ *     (ptr, N, H, W, C, cs): cs = floats per pixel (>= C, multiple of 4); channels [C, cs) are padding that
+ *     kernels keep at 0.0f.  ptr is 16-byte aligned.
+ *   - Conv weights are [Cout][kh][kw][Cin] (= torch OIHW in channels_last memory format, unpadded);
+ *     ConvTranspose2d weights are [Cin_t][kh][kw][Cout_t] (= torch IOHW channels_last).
+ *   - Every function enqueues on `stream` and returns immediately: 0 on success, negative on a bad
+ *     argument / launch failure (text via cat_hip_last_error()).  Nothing is allocated; scratch is passed in.
+ */
+#ifndef CAT_HIP_H
+#define CAT_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* cat_stream_t; /* hipStream_t */
+
+enum { CAT_PAD_ZERO = 0, CAT_PAD_REFLECT = 1 };
+enum { CAT_ACT_NONE = 0, CAT_ACT_RELU = 1, CAT_ACT_LRELU = 2, CAT_ACT_TANH = 3 };
+enum { CAT_NORM_INSTANCE = 0, CAT_NORM_BATCH = 1 };
+
+const char* cat_hip_last_error(void);
+int cat_hip_version(void);
+
+/* Dense convolution, geometry shared by fwd / dgrad / wgrad.
+ * Replaces nn.Conv2d (+ the nn.ReflectionPad2d in front of it) at models/modules/inception_modules.py:135-147,
+ * inception_architecture/inception_generator.py:37-56,130-131 and models/modules/discriminators.py:40-76. */
+typedef struct {
+  int N, H, W, Cin, xcs;   /* input  activation (H, W = unpadded input size) */
+  int Ho, Wo, Cout, ycs;   /* output activation */
+  int kh, kw, stride, pad; /* pad = implicit padding on each side */
+  int pad_mode;            /* CAT_PAD_ZERO | CAT_PAD_REFLECT */
+  int act;                 /* fused epilogue activation (fwd only) */
+  float slope;             /* LeakyReLU slope */
+  int ycw;                 /* fwd: channels [Cout, ycw) of y are written as 0 (ycw<=ycs); 0 -> Cout */
+} cat_conv_t;
+
+/* y = act(conv(x, w) + bias); bias may be NULL. */
+int cat_conv2d_fwd(const cat_conv_t* g, const float* x, const float* w, const float* bias, float* y,
+                   cat_stream_t stream);
+/* dx = conv^T(dy, w) with the geometry of the forward conv g.  For CAT_PAD_REFLECT the gradient w.r.t. the
+ * PADDED input is produced (dx has (H+2*pad) x (W+2*pad) pixels); fold it with cat_reflect_pad_bwd.
+ * Also serves as nn.ConvTranspose2d forward (inception_generator.py:120-126): bias/act then apply to dx.
+ * dxcw: channels [Cin, dxcw) of dx are zeroed. */
+int cat_conv2d_dgrad(const cat_conv_t* g, const float* dy, const float* w, const float* bias, float* dx,
+                     int dxcs, int dxcw, cat_stream_t stream);
+/* dw[Cout][kh][kw][Cin] (+)= sum_pixels dy * im2col(x).  `ws` is scratch of cat_conv2d_wgrad_ws_bytes(g) bytes.
+ * accumulate != 0 adds into dw (gradient accumulation over several backward calls). */
+size_t cat_conv2d_wgrad_ws_bytes(const cat_conv_t* g);
+int cat_conv2d_wgrad(const cat_conv_t* g, const float* x, const float* dy, float* dw, int accumulate, void* ws,
+                     cat_stream_t stream);
+
+/* Depthwise conv (groups == C), stride 1, weights [C][kh][kw]; replaces the groups=midp ConvBNReLU conv at
+ * inception_modules.py:166-173.  dgrad for reflect padding again yields the padded-input gradient. */
+int cat_dwconv2d_fwd(const cat_conv_t* g, const float* x, const float* w, const float* bias, float* y,
+                     cat_stream_t stream);
+int cat_dwconv2d_dgrad(const cat_conv_t* g, const float* dy, const float* w, float* dx, int dxcs,
+                       cat_stream_t stream);
+int cat_dwconv2d_wgrad(const cat_conv_t* g, const float* x, const float* dy, float* dw, int accumulate, void* ws,
+                       cat_stream_t stream);
+size_t cat_dwconv2d_wgrad_ws_bytes(const cat_conv_t* g);
+
+/* Backward of nn.ReflectionPad2d(pad): dx[N,H,W,C] = fold(dxp[N,H+2p,W+2p,C]). */
+int cat_reflect_pad_bwd(const float* dxp, float* dx, int N, int H, int W, int C, int cs, int pad,
+                        cat_stream_t stream);
+
+/* Per-channel sums over pixels: out[c] (+)= sum_m x[m*cs + c]  (conv bias gradient). */
+int cat_channel_sum(const float* x, int M, int C, int cs, float* out, int accumulate, void* ws, cat_stream_t stream);
+size_t cat_channel_sum_ws_bytes(int M, int cs);
+
+/* InstanceNorm2d / BatchNorm2d (training statistics), fused with the activation that follows them.
+ * Replaces norm_layer(...) + active_fn() at inception_modules.py:43-44 and networks.py:29-64 semantics:
+ * biased variance, eps inside the sqrt, BatchNorm running stats use the unbiased variance.
+ *   G = number of statistic groups (N for instance norm, 1 for batch norm); each group spans M/G pixels.
+ *   save_mean / save_rstd: [G][C] outputs kept for the backward pass.
+ *   running_mean / running_var: BatchNorm only, may be NULL.                                   */
+typedef struct {
+  int N, HW, C, cs;
+  int mode;          /* CAT_NORM_INSTANCE | CAT_NORM_BATCH */
+  float eps, momentum;
+  int act;           /* CAT_ACT_* applied after the affine */
+  float slope;
+} cat_norm_t;
+size_t cat_norm_ws_bytes(const cat_norm_t* g);
+int cat_norm_fwd(const cat_norm_t* g, const float* x, const float* gamma, const float* beta, float* y,
+                 float* save_mean, float* save_rstd, float* running_mean, float* running_var, void* ws,
+                 cat_stream_t stream);
+/* dx, dgamma (+)=, dbeta (+)= from dy (gradient w.r.t. the activated output), the saved pre-norm input x and
+ * the saved statistics.  gamma/dgamma/dbeta may be NULL (affine=False). */
+int cat_norm_bwd(const cat_norm_t* g, const float* x, const float* dy, const float* gamma, const float* beta,
+                 const float* save_mean, const float* save_rstd, float* dx, float* dgamma, float* dbeta,
+                 int accumulate, void* ws, cat_stream_t stream);
+/* Inference-mode norm: y = act(x * scale[c] + shift[c]) (BatchNorm eval with running stats folded by
+ * cat_bn_fold; used by the frozen teacher, distillers/base_inception_distiller.py:168). */
+int cat_bn_fold(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                float eps, int C, float* scale, float* shift, cat_stream_t stream);
+int cat_affine_act_fwd(const float* x, const float* scale, const float* shift, float* y, int64_t M, int C, int cs,
+                       int act, float slope, cat_stream_t stream);
+
+/* Elementwise: activations (fwd + bwd from the OUTPUT), n-ary add (the branch sum + residual of
+ * InvertedResidualChannels.forward, inception_modules.py:233-236), channel concat (torch.cat(...,1),
+ * distillers/base_inception_distiller.py:295-296) and its split backward. */
+int cat_act_fwd(const float* x, float* y, int64_t n, int act, float slope, cat_stream_t stream);
+int cat_act_bwd(const float* y, const float* dy, float* dx, int64_t n, int act, float slope, cat_stream_t stream);
+int cat_add_n(const float* const* srcs, int nsrc, float* dst, int64_t n, cat_stream_t stream);
+int cat_concat2(const float* a, int ca, int acs, const float* b, int cb, int bcs, float* y, int ycs, int64_t M,
+                cat_stream_t stream);
+int cat_slice_channels(const float* x, int xcs, int c0, int c, float* y, int ycs, int64_t M, cat_stream_t stream);
+
+/* Layout transposes at the boundary (images / checkpoints are NCHW in the reference). */
+int cat_nchw_to_nhwc(const float* x, float* y, int N, int C, int H, int W, int ycs, cat_stream_t stream);
+int cat_nhwc_to_nchw(const float* x, float* y, int N, int C, int H, int W, int xcs, cat_stream_t stream);
+
+/* Kernel alignment, utils/common.py:38-46.  X: [N][Dx], Y: [N][Dy] row-major (zero padding inside rows is
+ * harmless).  ws >= cat_ka_ws_bytes(N).  out[0] = KA; the N x N Grams stay in ws for the backward.
+ * cat_ka_bwd: dX = gout[0] * dKA/dX (same layout as X). */
+size_t cat_ka_ws_bytes(int N);
+int cat_ka_fwd(const float* X, int64_t Dx, const float* Y, int64_t Dy, int N, float* out, void* ws,
+               cat_stream_t stream);
+int cat_ka_bwd(const float* X, int64_t Dx, int N, const float* gout, const void* ws, float* dX, cat_stream_t stream);
+
+/* Scalar losses with their gradients (models/modules/loss.py:52-99, nn.L1Loss / nn.MSELoss):
+ *   kind 0: mean |a-b|      (L1, b tensor)          kind 1: mean (a-t)^2  (lsgan; t scalar target)
+ *   kind 2: -mean min(a-1,0)  (hinge D real)        kind 3: -mean min(-a-1,0) (hinge D fake)
+ *   kind 4: -mean a           (hinge G)              kind 5: mean (a-b)^2 (MSE vs tensor)
+ * Inputs are NHWC with (C, cs); the mean runs over M*C real elements.  out[0] = loss. */
+size_t cat_loss_ws_bytes(int64_t M);
+int cat_loss_fwd(int kind, const float* a, const float* b, float target, int64_t M, int C, int cs, float* out,
+                 void* ws, cat_stream_t stream);
+/* da = gout[0] * scale * dloss/da */
+int cat_loss_bwd(int kind, const float* a, const float* b, float target, int64_t M, int C, int cs,
+                 const float* gout, float scale, float* da, cat_stream_t stream);
+
+/* Adam step over one flat buffer (torch.optim.Adam semantics, base_inception_distiller.py:205-214):
+ * p, g, m, v: n floats; step = 1-based step count. */
+int cat_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                  float eps, float weight_decay, int step, float grad_scale, cat_stream_t stream);
+int cat_fill(float* p, int64_t n, float v, cat_stream_t stream);
+int cat_axpy(float* y, const float* x, int64_t n, float a, cat_stream_t stream); /* y += a*x */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

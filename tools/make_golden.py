@@ -1,0 +1,234 @@
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE (snap-research/CAT imported from /root/reference on CPU).
+
+Run in the build container only:  python tools/make_golden.py
+The fixtures hold inputs (or the seeds that rebuild them via oracle/detfill.py) and the reference's outputs; they pin
+the CPU oracle (oracle/ref_cpu.py) and, through it, the HIP path.  No reference source is stored."""
+import itertools
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+import ref_import  # noqa: E402
+
+ref_import.install()
+import torch  # noqa: E402
+from torch import nn  # noqa: E402
+from models import networks  # noqa: E402  (reference)
+from models.modules.loss import GANLoss  # noqa: E402
+from utils import common as uc  # noqa: E402
+from utils.model_profiling import model_profiling  # noqa: E402
+from distillers.inception_distiller import InceptionDistiller  # noqa: E402
+from torch.optim import Adam  # noqa: E402
+
+from oracle import detfill  # noqa: E402
+
+OUT = os.path.join(ROOT, 'tests', 'golden')
+os.makedirs(OUT, exist_ok=True)
+torch.set_num_threads(8)
+
+SEED_T, SEED_S, SEED_D, SEED_A, SEED_X = 11, 21, 41, 51, 31
+
+
+def sub(t, cmax=8, step=8):
+    """small deterministic sub-sample of an NCHW tensor"""
+    return t.detach()[:, :cmax, ::step, ::step].contiguous().numpy()
+
+
+def shapes_json(sd):
+    return json.dumps([[k, list(v.shape)] for k, v in sd.items()])
+
+
+def teacher(opt):
+    T = networks.define_G(3, 3, 64, 'inception_9blocks', opt.norm, 0, 'normal', 0.02, [], opt=opt)
+    T.load_state_dict(detfill.fill_state_dict(T.state_dict(), SEED_T, gamma_abs_normal=True))
+    T.eval()
+    return T
+
+
+def ref_distiller(opt, T, D):
+    """InceptionDistiller without its dataset / FID constructor (SURVEY §8c recipe step 5)."""
+    m = InceptionDistiller.__new__(InceptionDistiller)
+    m.opt, m.gpu_ids, m.isTrain, m.device = opt, [], True, torch.device('cpu')
+    m.loss_names = ['G_gan', 'G_distill', 'G_recon', 'D_fake', 'D_real']
+    m.netG_teacher, m.netD = T, D
+    m.netG_student = networks.define_G(3, 3, opt.student_ngf, 'inception_9blocks', opt.norm, 0, 'normal', 0.02, [], opt=opt)
+    m.criterionGAN = GANLoss(opt.gan_mode)
+    m.criterionRecon = torch.nn.L1Loss()
+    m.mapping_layers = ['down_sampling.9'] + ['features.%d' % i for i in range(2, 11, 3)]
+    m.netAs, m.Tacts, m.Sacts = [], {}, {}
+    gp = []
+    for i, n in enumerate(m.mapping_layers):
+        netA = nn.Conv2d(opt.student_ngf * 4, opt.teacher_ngf * 4, 1)
+        gp.append(netA.parameters())
+        m.netAs.append(netA)
+        m.loss_names.append('G_distill%d' % i)
+    m.optimizer_G = Adam([{'params': m.netG_student.parameters()}, {'params': itertools.chain(*gp)}], lr=opt.lr, betas=(opt.beta1, 0.999))
+    m.optimizer_D = Adam(D.parameters(), lr=opt.lr, betas=(opt.beta1, 0.999))
+    m.optimizers = [m.optimizer_G, m.optimizer_D]
+    m.add_mapping_hook()
+    return m
+
+
+def gamma_dump(T):
+    g = {'down': [T.down_sampling[i].weight.detach().clone() for i in (2, 5, 8)], 'up': [T.up_sampling[i].weight.detach().clone() for i in (1, 4)],
+         'blocks': []}
+    for blk in T.features:
+        g['blocks'].append(([bn.weight.detach().clone() for bn in blk.get_first_res_bn()],
+                            [bn.weight.detach().clone() for bn in blk.get_first_dw_bn()]))
+    return g
+
+
+def run_config(tag, norm, track, target, dataset_mode, gan_mode, ndf, lam_recon, lam_distill, size, nbatch):
+    opt = ref_import.make_opt(norm=norm, track=track, target_flops=target, dataset_mode=dataset_mode, gan_mode=gan_mode, ndf=ndf,
+                              lambda_recon=lam_recon, lambda_distill=lam_distill)
+    T = teacher(opt)
+    d_in = 6 if dataset_mode == 'aligned' else 3
+    D = networks.define_D(d_in, ndf, 'n_layers', 3, norm, 'normal', 0.02, [], opt=opt)
+    D.load_state_dict(detfill.fill_state_dict(D.state_dict(), SEED_D))
+    m = ref_distiller(opt, T, D)
+
+    # ---- shrink (utils/common.py:315-707) --------------------------------------------------------------
+    model_profiling(T, 256, 256, use_cuda=False, num_forwards=0, verbose=False)
+    t_macs = [T.n_macs, T.down_sampling.n_macs, T.features.n_macs, T.up_sampling.n_macs]
+    gam = gamma_dump(T)
+    import io
+    import contextlib
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        uc.shrink_model(m, target, opt)
+    line = [l for l in buf.getvalue().splitlines() if l.startswith('scale threshold')][0]
+    thr = np.float32(line.split('scale threshold: ')[1].split(',')[0])
+    S = m.netG_student
+    s_macs = [S.n_macs, S.down_sampling.n_macs, S.features.n_macs, S.up_sampling.n_macs]
+    cfg = {'down': [S.down_sampling[i].num_features for i in (2, 5, 8)], 'up': [S.up_sampling[i].num_features for i in (1, 4)],
+           'blocks': [[b.res_channels, b.dw_channels] for b in S.features]}
+    sh = {'thr': thr, 'target': np.float64(target), 't_macs': np.array(t_macs, dtype=np.int64), 's_macs': np.array(s_macs, dtype=np.int64),
+          'cfg': json.dumps(cfg), 'student_shapes': shapes_json(S.state_dict()), 'prune_cin_lb': np.int64(opt.prune_cin_lb),
+          'norm': norm, 'track': np.bool_(track)}
+    for i, g in enumerate(gam['down']):
+        sh[f'g_down{i}'] = g.numpy()
+    for i, g in enumerate(gam['up']):
+        sh[f'g_up{i}'] = g.numpy()
+    for b, (res, dw) in enumerate(gam['blocks']):
+        for j, g in enumerate(res):
+            sh[f'g_b{b}_res{j}'] = g.numpy()
+        for j, g in enumerate(dw):
+            sh[f'g_b{b}_dw{j}'] = g.numpy()
+    # copied (masked) weights: a few tensors prove the mask / index selection bit-exactly
+    ssd = S.state_dict()
+    for k in ['down_sampling.1.weight', 'down_sampling.4.weight', 'down_sampling.8.weight', 'features.0.res_ops.1.1.0.weight',
+              'features.0.res_ops.1.4.weight', 'features.3.dw_ops.2.2.0.weight', 'features.8.dw_ops.0.4.weight', 'up_sampling.0.weight',
+              'up_sampling.3.weight', 'up_sampling.7.weight']:
+        if k in ssd:
+            sh['copied:' + k] = ssd[k].numpy().copy()
+    np.savez_compressed(os.path.join(OUT, f'shrink_{tag}.npz'), **sh)
+    print(tag, 'shrink: thr', thr, 'student macs', s_macs[0], 'down', cfg['down'], 'up', cfg['up'], 'block0', cfg['blocks'][0])
+
+    # ---- student forward (trainer.py:106-107 re-initialises the pruned student; here: deterministic fill) --------
+    S.load_state_dict(detfill.fill_state_dict(S.state_dict(), SEED_S))
+    for i, a in enumerate(m.netAs):
+        a.load_state_dict(detfill.fill_state_dict(a.state_dict(), SEED_A + i))
+    S.train()
+    x = detfill.images((1, 3, 256, 256), SEED_X)
+    m.Sacts.clear()
+    s_before = {k: v.clone() for k, v in S.state_dict().items()}
+    with torch.no_grad():
+        y = S(x)
+    S.load_state_dict(s_before)     # a train-mode forward moves BatchNorm running stats; the step fixture starts fresh
+    fw = {'out': sub(y, 3, 8), 'student_shapes': shapes_json(S.state_dict())}
+    for k, v in m.Sacts.items():
+        fw['act:' + k.replace('cpu', '')] = sub(v, 8, 8)
+    m.Tacts.clear()
+    xt = detfill.images((1, 3, size, size), SEED_X + 1)
+    with torch.no_grad():
+        yt = T(xt)
+    fw['teacher_out'] = sub(yt, 3, 4)
+    for k, v in m.Tacts.items():
+        fw['tact:' + k.replace('cpu', '')] = sub(v, 8, 4)
+    # discriminator forward (train mode)
+    xd = detfill.images((nbatch, d_in, size, size), SEED_X + 2)
+    D.train()
+    d_before = {k: v.clone() for k, v in D.state_dict().items()}
+    with torch.no_grad():
+        fw['disc_out'] = D(xd).numpy()
+    D.load_state_dict(d_before)
+    np.savez_compressed(os.path.join(OUT, f'forward_{tag}.npz'), **fw)
+
+    # ---- two full optimize_parameters steps (inception_distiller.py:179-188) ----------------------------------
+    st = {}
+    probe_S = ['down_sampling.1.weight', 'down_sampling.2.weight', 'features.0.res_ops.2.1.0.weight', 'features.4.dw_ops.1.2.0.weight',
+               'features.8.pw_bn.bias', 'up_sampling.0.weight', 'up_sampling.7.weight', 'up_sampling.7.bias']
+    probe_D = ['model.0.weight', 'model.0.bias', 'model.2.weight', 'model.3.weight', 'model.8.weight', 'model.11.weight']
+    for step in range(2):
+        A = detfill.images((nbatch, 3, size, size), SEED_X + 10 + step)
+        B = detfill.images((nbatch, 3, size, size), SEED_X + 20 + step)
+        m.set_input({'A': A, 'B': B, 'A_paths': [], 'B_paths': []})
+        m.optimize_parameters(step)
+        for k, v in m.get_current_losses().items():
+            st[f'loss{step}:{k}'] = np.float64(v)
+        st[f'Sfake{step}'] = sub(m.Sfake_B, 3, 4)
+        ssd, dsd = S.state_dict(), D.state_dict()
+        for k in probe_S:
+            st[f'S{step}:{k}'] = ssd[k].reshape(-1)[:64].numpy().copy()
+        for k in probe_D:
+            if k in dsd:
+                st[f'D{step}:{k}'] = dsd[k].reshape(-1)[:64].numpy().copy()
+        for k in dsd:
+            if k.endswith('running_mean') or k.endswith('running_var'):
+                st[f'D{step}:{k}'] = dsd[k].reshape(-1)[:16].numpy().copy()
+        for k in ssd:
+            if k in ('down_sampling.2.running_mean', 'down_sampling.2.running_var', 'features.0.pw_bn.running_var'):
+                st[f'S{step}:{k}'] = ssd[k].reshape(-1)[:16].numpy().copy()
+    st['meta'] = json.dumps(dict(norm=norm, track=track, dataset_mode=dataset_mode, gan_mode=gan_mode, ndf=ndf, lambda_recon=lam_recon,
+                                 lambda_distill=lam_distill, lambda_gan=1.0, size=size, nbatch=nbatch, lr=opt.lr, beta1=opt.beta1,
+                                 target=target))
+    st['student_shapes'] = shapes_json(S.state_dict())
+    np.savez_compressed(os.path.join(OUT, f'step_{tag}.npz'), **st)
+    print(tag, 'step losses', {k: float(v) for k, v in st.items() if k.startswith('loss1')})
+
+
+def small_ops():
+    out = {}
+    for n in (2, 3, 16):
+        X = detfill.normal((n, 7, 6, 5), 100 + n).requires_grad_(True)
+        Y = detfill.normal((n, 11, 6, 5), 200 + n)
+        v = uc.KA(X, Y)
+        v.backward()
+        out[f'ka{n}'] = np.float64(v.item())
+        out[f'ka{n}_grad'] = X.grad.numpy().copy()
+    pred = detfill.normal((2, 1, 6, 6), 300, 1.5)
+    for mode in ('hinge', 'lsgan'):
+        crit = GANLoss(mode)
+        for real in (True, False):
+            p = pred.clone().requires_grad_(True)
+            l = crit(p, real, for_discriminator=True)
+            l.backward()
+            out[f'gan_{mode}_D_{int(real)}'] = np.float64(l.item())
+            out[f'gan_{mode}_D_{int(real)}_grad'] = p.grad.numpy().copy()
+        p = pred.clone().requires_grad_(True)
+        l = crit(p, True, for_discriminator=False)
+        l.backward()
+        out[f'gan_{mode}_G'] = np.float64(l.item())
+        out[f'gan_{mode}_G_grad'] = p.grad.numpy().copy()
+    # multiscale list form (loss.py:71-82)
+    preds = [[detfill.normal((2, 4, 5, 5), 310), detfill.normal((2, 1, 5, 5), 311)], [detfill.normal((2, 4, 3, 3), 312), detfill.normal((2, 1, 3, 3), 313)]]
+    crit = GANLoss('hinge')
+    out['gan_hinge_list_D_1'] = crit(preds, True, True).numpy().copy()
+    out['gan_hinge_list_D_0'] = crit(preds, False, True).numpy().copy()
+    out['gan_hinge_list_G'] = crit(preds, True, False).numpy().copy()
+    np.savez_compressed(os.path.join(OUT, 'small_ops.npz'), **out)
+    print('small ops done')
+
+
+if __name__ == '__main__':
+    small_ops()
+    # C3-like: CycleGAN student (InstanceNorm affine, lsgan, unaligned, ndf 64, lambda_recon 5), SURVEY §8d
+    run_config('in', 'instance', False, 2.6e9, 'unaligned', 'lsgan', 64, 5.0, 1.0, 64, 2)
+    # C2-like: pix2pix student (BatchNorm + running stats, hinge, aligned, ndf 128, lambda_recon 100, lambda_distill 1.3)
+    run_config('bn', 'batch', True, 4.6e9, 'aligned', 'hinge', 128, 100.0, 1.3, 64, 2)
