@@ -1,0 +1,284 @@
+"""GPU parity of every HIP kernel family against the CPU oracle ops (stock fp32 ATen on the host), called through the
+C-ABI (cat_amd.ops -> ctypes -> libcat_hip.so).  Tolerance: 1e-3 relative (north_star); observed ~1e-6..1e-5."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import detfill, ref_cpu
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def rel(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+@pytest.fixture(scope='module')
+def dev():
+    from cat_amd import _lib
+    _lib.load()
+    return torch.device('cuda:0')
+
+
+def _nhwc(x, dev, requires_grad=False):
+    from cat_amd import ops
+    y = ops.to_nhwc(x.to(dev))
+    if requires_grad:
+        y = y.detach().requires_grad_(True)
+    return y
+
+
+def _cl(w, dev):
+    w = w.to(dev)
+    if w.dim() == 4 and w.shape[1] > 1:
+        w = w.contiguous(memory_format=torch.channels_last)
+    return w.detach().requires_grad_(True)
+
+
+CONV_CASES = [
+    # cin, cout, k, stride, pad, reflect, act, N, H, W
+    (3, 16, 7, 1, 3, True, 0, 2, 20, 24),
+    (16, 35, 3, 2, 1, False, 0, 2, 20, 24),
+    (54, 7, 5, 1, 2, True, 0, 2, 16, 16),
+    (54, 13, 1, 1, 0, False, 0, 3, 9, 11),
+    (13, 54, 5, 1, 2, True, 0, 2, 16, 12),
+    (6, 128, 4, 2, 1, False, 2, 2, 32, 32),
+    (128, 256, 4, 2, 1, False, 0, 2, 16, 16),
+    (64, 1, 4, 1, 1, False, 0, 2, 9, 9),
+    (16, 3, 7, 1, 3, True, 3, 1, 18, 18),
+    (256, 42, 3, 1, 1, True, 0, 1, 12, 12),
+    (42, 256, 3, 1, 1, True, 0, 1, 12, 12),
+    (82, 100, 3, 1, 1, False, 0, 1, 10, 10),
+    (130, 17, 1, 1, 0, False, 0, 1, 8, 8),
+    (5, 5, 3, 2, 1, False, 0, 1, 7, 9),       # odd sizes, stride 2
+]
+
+
+@pytest.mark.parametrize('cin,cout,k,stride,pad,reflect,act,n,h,w', CONV_CASES)
+def test_conv2d_fwd_bwd(dev, cin, cout, k, stride, pad, reflect, act, n, h, w):
+    from cat_amd import ops
+    x = detfill.normal((n, cin, h, w), 1)
+    wt = detfill.normal((cout, cin, k, k), 2, 1.0 / np.sqrt(cin * k * k))
+    b = detfill.normal((cout,), 3, 0.1)
+    xr, wr, br = x.clone().requires_grad_(True), wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    xp = F.pad(xr, (pad,) * 4, mode='reflect') if reflect and pad else xr
+    yr = F.conv2d(xp, wr, br, stride=stride, padding=0 if reflect else pad)
+    if act == 2:
+        yr = F.leaky_relu(yr, 0.2)
+    elif act == 3:
+        yr = torch.tanh(yr)
+    gy = detfill.normal(tuple(yr.shape), 4)
+    yr.backward(gy)
+
+    xg, wg, bg = _nhwc(x, dev, True), _cl(wt, dev), b.to(dev).requires_grad_(True)
+    y = ops.Conv2dFn.apply(xg, wg, bg, stride, pad, 1 if reflect else 0, act, 0.2)
+    assert y.shape == yr.shape
+    assert rel(y, yr) < TOL
+    # padding channels of the NHWC buffer stay zero
+    cs = ops.act_cs(y)
+    full = torch.as_strided(y, (y.shape[0], cs, y.shape[2], y.shape[3]), y.stride())
+    assert float(full[:, cout:].abs().max()) == 0.0 if cs > cout else True
+    y.backward(_nhwc(gy, dev))
+    assert rel(xg.grad, xr.grad) < TOL
+    assert rel(wg.grad, wr.grad) < TOL
+    assert rel(bg.grad, br.grad) < TOL
+
+
+@pytest.mark.parametrize('cin,cout,n,h,w', [(54, 33, 2, 8, 8), (256, 128, 1, 8, 6), (33, 16, 2, 9, 7), (4, 4, 1, 3, 3)])
+def test_conv_transpose2d(dev, cin, cout, n, h, w):
+    from cat_amd import ops
+    x = detfill.normal((n, cin, h, w), 5)
+    wt = detfill.normal((cin, cout, 3, 3), 6, 1.0 / np.sqrt(cin * 9))
+    b = detfill.normal((cout,), 7, 0.1)
+    xr, wr, br = x.clone().requires_grad_(True), wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.conv_transpose2d(xr, wr, br, stride=2, padding=1, output_padding=1)
+    gy = detfill.normal(tuple(yr.shape), 8)
+    yr.backward(gy)
+    xg, wg, bg = _nhwc(x, dev, True), _cl(wt, dev), b.to(dev).requires_grad_(True)
+    y = ops.ConvTranspose2dFn.apply(xg, wg, bg, 2, 1, 1)
+    assert y.shape == yr.shape and rel(y, yr) < TOL
+    y.backward(_nhwc(gy, dev))
+    assert rel(xg.grad, xr.grad) < TOL
+    assert rel(wg.grad, wr.grad) < TOL
+    assert rel(bg.grad, br.grad) < TOL
+
+
+@pytest.mark.parametrize('c,k,reflect,n,h,w', [(11, 3, True, 2, 12, 10), (14, 5, True, 2, 9, 9), (8, 1, False, 2, 6, 6), (42, 5, True, 1, 16, 16),
+                                               (17, 3, False, 1, 7, 5)])
+def test_depthwise_conv(dev, c, k, reflect, n, h, w):
+    from cat_amd import ops
+    pad = (k - 1) // 2
+    x = detfill.normal((n, c, h, w), 9)
+    wt = detfill.normal((c, 1, k, k), 10, 1.0 / k)
+    b = detfill.normal((c,), 11, 0.1)
+    xr, wr, br = x.clone().requires_grad_(True), wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    xp = F.pad(xr, (pad,) * 4, mode='reflect') if reflect and pad else xr
+    yr = F.conv2d(xp, wr, br, padding=0 if reflect else pad, groups=c)
+    gy = detfill.normal(tuple(yr.shape), 12)
+    yr.backward(gy)
+    xg, wg, bg = _nhwc(x, dev, True), wt.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    y = ops.DwConv2dFn.apply(xg, wg, bg, pad, 1 if reflect else 0)
+    assert rel(y, yr) < TOL
+    y.backward(_nhwc(gy, dev))
+    assert rel(xg.grad, xr.grad) < TOL
+    assert rel(wg.grad, wr.grad) < TOL
+    assert rel(bg.grad, br.grad) < TOL
+
+
+@pytest.mark.parametrize('mode,c,n,h,w,act', [('instance', 54, 2, 16, 16, 1), ('instance', 7, 3, 9, 5, 1), ('batch', 77, 4, 8, 8, 1),
+                                              ('batch', 256, 2, 6, 6, 2), ('instance', 1024, 1, 5, 5, 2), ('batch', 16, 2, 64, 64, 0),
+                                              ('instance', 1100, 1, 4, 4, 0)])
+def test_norm_fwd_bwd(dev, mode, c, n, h, w, act):
+    from cat_amd import ops, _lib as L
+    x = detfill.normal((n, c, h, w), 13) * 2.0 + 3.0      # non-zero mean: exercises the shifted-sum variance
+    ga = 1.0 + 0.2 * detfill.normal((c,), 14)
+    be = 0.1 * detfill.normal((c,), 15)
+    xr, gr, br = x.clone().requires_grad_(True), ga.clone().requires_grad_(True), be.clone().requires_grad_(True)
+    rm, rv = torch.zeros(c), torch.ones(c)
+    if mode == 'instance':
+        yr = F.instance_norm(xr, None, None, gr, br, True, 0.1, 1e-5)
+    else:
+        yr = F.batch_norm(xr, rm, rv, gr, br, True, 0.1, 1e-5)
+    yr = F.relu(yr) if act == 1 else (F.leaky_relu(yr, 0.2) if act == 2 else yr)
+    gy = detfill.normal(tuple(yr.shape), 16)
+    yr.backward(gy)
+    xg = _nhwc(x, dev, True)
+    gg, bg = ga.to(dev).requires_grad_(True), be.to(dev).requires_grad_(True)
+    rmg, rvg = torch.zeros(c, device=dev), torch.ones(c, device=dev)
+    y = ops.NormActFn.apply(xg, gg, bg, rmg if mode == 'batch' else None, rvg if mode == 'batch' else None,
+                            L.NORM_INSTANCE if mode == 'instance' else L.NORM_BATCH, 1e-5, 0.1, act, 0.2)
+    assert rel(y, yr) < TOL
+    if mode == 'batch':
+        assert rel(rmg, rm) < TOL and rel(rvg, rv) < TOL
+    y.backward(_nhwc(gy, dev))
+    assert rel(xg.grad, xr.grad) < 5 * TOL
+    assert rel(gg.grad, gr.grad) < TOL
+    assert rel(bg.grad, br.grad) < TOL
+
+
+def test_bn_eval_affine(dev):
+    from cat_amd import ops
+    c = 42
+    x = detfill.normal((2, c, 8, 8), 17)
+    ga, be = 1.0 + 0.2 * detfill.normal((c,), 18), 0.1 * detfill.normal((c,), 19)
+    rm, rv = 0.1 * detfill.normal((c,), 20), 0.5 + torch.rand(c)
+    yr = F.relu(F.batch_norm(x, rm, rv, ga, be, False, 0.1, 1e-5))
+    scale, shift = ops.bn_fold(ga.to(dev), be.to(dev), rm.to(dev), rv.to(dev), 1e-5)
+    with torch.no_grad():
+        y = ops.affine_act(_nhwc(x, dev), scale, shift, 1, 0.0)
+    assert rel(y, yr) < TOL
+
+
+@pytest.mark.parametrize('n,cx,cy,h,w', [(2, 7, 11, 6, 5), (3, 54, 256, 16, 16), (16, 56, 256, 16, 16), (17, 5, 9, 8, 8), (1, 8, 8, 4, 4)])
+def test_ka(dev, n, cx, cy, h, w):
+    from cat_amd import ops
+    X, Y = detfill.normal((n, cx, h, w), 100 + n), detfill.normal((n, cy, h, w), 200 + n)
+    Xr = X.clone().requires_grad_(True)
+    vr = ref_cpu.ka(Xr, Y)
+    (-1.3 * vr).backward()
+    Xg = _nhwc(X, dev, True)
+    v = ops.ka(Xg, _nhwc(Y, dev))
+    assert abs(v.item() - vr.item()) < 1e-5
+    torch.autograd.backward([v], [torch.full((), -1.3, device=dev)])
+    if n == 1:      # KA == 1 identically: the gradient is pure round-off on both sides
+        assert float(Xg.grad.abs().max()) < 1e-6 and float(Xr.grad.abs().max()) < 1e-6
+        return
+    assert rel(Xg.grad, Xr.grad) < 5 * TOL
+
+
+def test_ka_matches_reference_golden(dev):
+    import helpers as H
+    from cat_amd import ops
+    g = H.load('small_ops.npz')
+    for n in (2, 3, 16):
+        X = detfill.normal((n, 7, 6, 5), 100 + n)
+        Y = detfill.normal((n, 11, 6, 5), 200 + n)
+        Xg = _nhwc(X, dev, True)
+        v = ops.ka(Xg, _nhwc(Y, dev))
+        v.backward()
+        assert abs(v.item() - float(g[f'ka{n}'])) < 1e-5
+        assert rel(Xg.grad, torch.from_numpy(g[f'ka{n}_grad'])) < 5 * TOL
+
+
+def test_gan_and_recon_losses(dev):
+    import helpers as H
+    from cat_amd.loss import GANLoss, L1Loss, MSELoss
+    g = H.load('small_ops.npz')
+    pred = detfill.normal((2, 1, 6, 6), 300, 1.5)
+    for mode in ('hinge', 'lsgan'):
+        crit = GANLoss(mode)
+        for real in (True, False):
+            p = _nhwc(pred, dev, True)
+            l = crit(p, real, for_discriminator=True)
+            l.backward()
+            assert abs(l.item() - float(g[f'gan_{mode}_D_{int(real)}'])) < 1e-6
+            assert rel(p.grad, torch.from_numpy(g[f'gan_{mode}_D_{int(real)}_grad'])) < 1e-6
+        p = _nhwc(pred, dev, True)
+        l = crit(p, True, for_discriminator=False)
+        l.backward()
+        assert abs(l.item() - float(g[f'gan_{mode}_G'])) < 1e-6
+        assert rel(p.grad, torch.from_numpy(g[f'gan_{mode}_G_grad'])) < 1e-6
+    a, b = detfill.normal((2, 3, 16, 16), 301), detfill.normal((2, 3, 16, 16), 302)
+    for crit, ref in ((L1Loss(), F.l1_loss), (MSELoss(), F.mse_loss)):
+        ar = a.clone().requires_grad_(True)
+        lr = ref(ar, b)
+        lr.backward()
+        ag = _nhwc(a, dev, True)
+        l = crit(ag, _nhwc(b, dev))
+        l.backward()
+        assert abs(l.item() - lr.item()) < 1e-6 and rel(ag.grad, ar.grad) < 1e-6
+
+
+def test_adam_matches_torch(dev):
+    from cat_amd.optim import FusedAdam
+    torch.manual_seed(0)
+    ps = [torch.nn.Parameter(detfill.normal(s, 400 + i)) for i, s in enumerate([(7, 5, 3, 3), (11,), (4, 1, 5, 5)])]
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    oref = torch.optim.Adam(ref, lr=2e-4, betas=(0.5, 0.999))
+    gp = [torch.nn.Parameter(p.detach().clone().to(dev)) for p in ps]
+    opt = FusedAdam(gp, lr=2e-4, betas=(0.5, 0.999))
+    for step in range(3):
+        grads = [detfill.normal(tuple(p.shape), 500 + 10 * step + i) for i, p in enumerate(ps)]
+        opt.zero_grad()
+        for p, r, g in zip(gp, ref, grads):
+            r.grad = g.clone()
+            p.grad.copy_(g.to(dev))
+        oref.step()
+        opt.step()
+        for p, r in zip(gp, ref):
+            assert rel(p, r) < 1e-6
+
+
+def test_layout_add_concat(dev):
+    from cat_amd import ops
+    x = detfill.normal((2, 5, 7, 9), 600)
+    xg = ops.to_nhwc(x.to(dev))
+    assert ops.is_act(xg) and torch.equal(xg.cpu(), x)
+    assert torch.equal(ops.to_nchw(xg).cpu(), x)
+    ys = [detfill.normal((2, 5, 7, 9), 601 + i) for i in range(7)]
+    s = ops.AddNFn.apply(*[_nhwc(y, dev) for y in ys])
+    assert rel(s, sum(ys)) < 1e-6
+    a, b = detfill.normal((2, 3, 8, 8), 610), detfill.normal((2, 3, 8, 8), 611)
+    ag, bg = _nhwc(a, dev, True), _nhwc(b, dev, True)
+    c = ops.Concat2Fn.apply(ag, bg)
+    assert torch.equal(c.cpu(), torch.cat((a, b), 1))
+    gy = detfill.normal((2, 6, 8, 8), 612)
+    c.backward(_nhwc(gy, dev))
+    assert torch.equal(ag.grad.cpu(), gy[:, :3]) and torch.equal(bg.grad.cpu(), gy[:, 3:])
+    # fan-out: gradients of the aliases are summed by one kernel
+    xg = _nhwc(x, dev, True)
+    outs = ops.fanout(xg, 10)
+    gs = [detfill.normal((2, 5, 7, 9), 620 + i) for i in range(10)]
+    torch.autograd.backward(list(outs), [_nhwc(g, dev) for g in gs])
+    assert rel(xg.grad, sum(gs)) < 1e-6
+
+
+def test_errors_are_loud(dev):
+    from cat_amd import ops
+    with pytest.raises(RuntimeError):
+        ops.Conv2dFn.apply(torch.zeros(1, 3, 8, 8), torch.zeros(4, 3, 3, 3), None, 1, 1, 0, 0, 0.0)   # CPU tensor: no fallback
+    with pytest.raises(RuntimeError):
+        ops.Conv2dFn.apply(torch.zeros(1, 3, 8, 8, device=dev), torch.zeros(4, 5, 3, 3, device=dev), None, 1, 1, 0, 0, 0.0)
