@@ -1,0 +1,210 @@
+#!/usr/bin/env python
+"""bench.py — distill-step images/sec of the MI355X build on BASELINE.json's headline workload.
+
+  python bench.py --gpus N --steps K --warmup W          (N=1)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W   (N>1)
+
+Workload (BASELINE configs[1]): pix2pix InceptionDistiller.optimize_parameters at 256x256, per-GPU batch
+16 -- frozen teacher ngf 64 (BatchNorm, running stats), student pruned by shrink_model to 4.6e9 MACs and re-initialised,
+PatchGAN 6ch ndf 128, hinge GAN + L1*100 + KA*1.3, two Adam steps.  Synthetic N(0,1).tanh() images, random-init
+weights of the named architecture, fp32 everywhere.  Data parallel = one process per GPU, batch sharded (weak scaling:
+per-GPU batch fixed), RCCL all-reduce of the gradient buckets.
+
+The JSON line carries `roofline` for the dominant kernel family (the fp32-MFMA implicit-GEMM convolutions; achieved =
+algorithmic FLOPs / HIP-event time of those launches, measured in a short pass after the timed region so the events do
+not perturb `value`) and `cpu_baseline` (the CPU oracle timed on a bounded sample of the same workload on rank 0)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+import torch  # noqa: E402
+
+MFMA_F32_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 256 CUs @ 2.4 GHz
+
+
+def build_model(args, device_index):
+    import helpers as H
+    from oracle import detfill
+    from cat_amd import networks, prune
+    from cat_amd.distillers import create_distiller
+    opt = H.make_opt(norm='batch', track=True, ndf=128, dataset_mode='aligned', gan_mode='hinge', lambda_recon=100.0, lambda_distill=1.3,
+                     target_flops=args.target_flops, prune_cin_lb=16, student_ngf=32, gpu_ids=[device_index],
+                     data_height=args.size, data_width=args.size)
+    torch.manual_seed(233)
+    model = create_distiller(opt, verbose=False)
+    # canonical teacher: deterministic weights, |N(0,1)| norm scales (a trained teacher's scales are non-uniform)
+    model.netG_teacher.load_state_dict(detfill.fill_state_dict(model.netG_teacher.state_dict(), H.SEED_T, gamma_abs_normal=True))
+    model.setup(opt, verbose=False)
+    # student shapes are defined at 256x256 like the reference's launch scripts (data_height is the dataset's size)
+    opt.data_height = opt.data_width = 256
+    prune.shrink(model, opt)                                                              # trainer.py:106
+    model.netG_student = networks.init_net(model.netG_student, opt.init_type, opt.init_gain, []).to(model.device)   # trainer.py:107-109
+    model.remove_mapping_hook()
+    import itertools
+    from cat_amd.optim import FusedAdam
+    gp = [a.parameters() for a in model.netAs]
+    model.optimizer_G = FusedAdam([{'params': model.netG_student.parameters()}, {'params': itertools.chain(*gp)}], lr=opt.lr,
+                                  betas=(opt.beta1, 0.999))
+    model.optimizers = [model.optimizer_G, model.optimizer_D]
+    model.add_mapping_hook()
+    model.netG_student.train()
+    model.netD.train()
+    return model, opt
+
+
+def cpu_baseline(opt, model, args):
+    """The CPU oracle (a port: plain PyTorch ATen ops, same algorithm) on a bounded sample: batch 2 at the bench
+    resolution, 1 warm-up + 2 timed steps (~10-30 s of host work)."""
+    import helpers as H
+    from oracle import detfill, ref_cpu
+    nb = 2
+    ncfg = H.cfg_for('batch')
+    cfg = dict(T=ncfg, S=ncfg, D=ncfg, dataset_mode='aligned', gan_mode='hinge', lambda_recon=100.0, lambda_distill=1.3, lambda_gan=1.0,
+               lr=opt.lr, beta1=opt.beta1)
+    cpu = lambda net: {k: v.detach().cpu().contiguous().clone() for k, v in net.state_dict().items()}
+    st = ref_cpu.DistillState(cpu(model.netG_teacher), cpu(model.netG_student), cpu(model.netD), cfg)
+    cores = torch.get_num_threads()
+    A = detfill.images((nb, 3, args.size, args.size), 1)
+    B = detfill.images((nb, 3, args.size, args.size), 2)
+    ref_cpu.distill_step(st, A, B)
+    t0 = time.perf_counter()
+    reps = 2
+    for _ in range(reps):
+        ref_cpu.distill_step(st, A, B)
+    dt = time.perf_counter() - t0
+    return {'value': round(nb * reps / dt, 4), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
+            'sample': f'oracle/ref_cpu.distill_step, batch {nb} @ {args.size}x{args.size}, 1 warm-up + {reps} timed steps, '
+                      f'{cores} torch threads'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=16, help='per-GPU batch (BASELINE: 16)')
+    ap.add_argument('--size', type=int, default=256)
+    ap.add_argument('--target-flops', type=float, default=4.6e9, dest='target_flops')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-profile', action='store_true')
+    ap.add_argument('--no-overlap', action='store_true')
+    args = ap.parse_args()
+
+    from cat_amd import _lib, ops, parallel
+    _lib.load()
+    rank, world, local = parallel.init_distributed()
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}')
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: the product path is HIP-only')
+    os.environ['LOCAL_RANK'] = str(local)
+    torch.cuda.set_device(local)
+    from oracle import detfill
+    model, opt = build_model(args, local)
+    if world > 1:
+        model.enable_data_parallel(parallel.DataParallelReducer(), overlap=not args.no_overlap)
+
+    # synthetic batches, resident in HBM before the timed region (global batch = batch * world; this rank's shard)
+    nbuf = 4
+    batches = []
+    for i in range(nbuf):
+        A = detfill.images((args.batch, 3, args.size, args.size), 1000 + 10 * i + rank).cuda()
+        B = detfill.images((args.batch, 3, args.size, args.size), 2000 + 10 * i + rank).cuda()
+        batches.append({'A': A, 'B': B, 'A_paths': [], 'B_paths': []})
+
+    def step(i):
+        model.set_input(batches[i % nbuf])
+        model.optimize_parameters(i)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    if world > 1:
+        model.finish_pending()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        dt = model.dp.max_over_ranks(dt)
+    losses = model.get_current_losses()
+    assert all(v == v for v in losses.values()), 'NaN loss'
+    assert ops.STATS['conform_copies'] == 0
+
+    roofline = None
+    if not args.no_kernel_profile and rank == 0:
+        roofline = kernel_roofline(model, step, args)
+    if world > 1:
+        torch.distributed.barrier()
+
+    ips = args.batch * world * args.steps / dt
+    out = {
+        'metric': 'distill-step images/sec @256x256 bs=16', 'value': round(ips, 3), 'unit': 'images/sec', 'n_gpus': world,
+        'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * dt / args.steps, 3), 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'pix2pix InceptionDistiller.optimize_parameters (BASELINE configs[1]): teacher ngf64 frozen + student '
+                               f'pruned to {args.target_flops:.2g} MACs + PatchGAN ndf128, hinge + L1 + KA, Adam x2',
+                   'image': f'{args.size}x{args.size}', 'per_gpu_batch': args.batch, 'global_batch': args.batch * world,
+                   'parallelism': f'dp{world}', 'student_n_macs': int(model.netG_student.n_macs)},
+        'roofline': roofline,
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(opt, model, args)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+def kernel_roofline(model, step, args):
+    """HIP-event timing of every implicit-GEMM conv launch (events recorded on the launch stream by libcat_hip's
+    profiling hook) over a few extra steps; achieved = algorithmic conv FLOPs / summed kernel time."""
+    from cat_amd import _lib
+    lib = _lib.load()
+    if not hasattr(lib, 'cat_prof_enable'):
+        return None
+    import ctypes as C
+    nsteps = 2
+    lib.cat_prof_enable(1)
+    for i in range(nsteps):
+        step(10_000 + i)
+    torch.cuda.synchronize()
+    n = lib.cat_prof_collect()
+    lib.cat_prof_enable(0)
+    fams = {}
+    name = C.create_string_buffer(64)
+    cnt, ms, fl = C.c_int64(), C.c_double(), C.c_double()
+    for i in range(n):
+        lib.cat_prof_family(i, name, 64, C.byref(cnt), C.byref(ms), C.byref(fl))
+        fams[name.value.decode()] = {'launches_per_step': cnt.value / nsteps, 'ms_per_step': ms.value / nsteps,
+                                     'gflop_per_step': fl.value / 1e9 / nsteps}
+    conv = {k: v for k, v in fams.items() if k.startswith('conv')}
+    if not conv:
+        return None
+    dom = max(conv, key=lambda k: conv[k]['ms_per_step'])
+    tot_ms = sum(v['ms_per_step'] for v in conv.values())
+    tot_gf = sum(v['gflop_per_step'] for v in conv.values())
+    d = conv[dom]
+    achieved = d['gflop_per_step'] / d['ms_per_step'] if d['ms_per_step'] > 0 else 0.0   # GFLOP/ms == TFLOP/s
+    return {'bound': 'mfma', 'kernel': dom, 'achieved': round(achieved, 3), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': round(achieved / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': None,
+            'avg_launch_us': round(1e3 * d['ms_per_step'] / max(d['launches_per_step'], 1), 3),
+            'all_conv': {'achieved': round(tot_gf / tot_ms, 3) if tot_ms else 0.0, 'ms_per_step': round(tot_ms, 3),
+                         'gflop_per_step': round(tot_gf, 2)},
+            'families': {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in fams.items()}}
+
+
+if __name__ == '__main__':
+    main()

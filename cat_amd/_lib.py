@@ -63,6 +63,10 @@ SIGNATURES = {
     'cat_loss_fwd': (c_i, [c_i, c_p, c_p, c_f, c_l, c_i, c_i, c_p, c_p, c_p]),
     'cat_loss_bwd': (c_i, [c_i, c_p, c_p, c_f, c_l, c_i, c_i, c_p, c_f, c_p, c_p]),
     'cat_adam_step': (c_i, [c_p, c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_f, c_i, c_f, c_p]),
+    'cat_prof_enable': (None, [c_i]),
+    'cat_prof_collect': (c_i, []),
+    'cat_prof_family': (c_i, [c_i, C.c_char_p, c_i, C.POINTER(c_l), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    'cat_prof_family_bytes': (C.c_double, [c_i]),
     'cat_fill': (c_i, [c_p, c_l, c_f, c_p]),
     'cat_axpy': (c_i, [c_p, c_p, c_l, c_f, c_p]),
 }

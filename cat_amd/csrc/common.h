@@ -12,6 +12,19 @@ namespace cat {
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
 
+// Optional HIP-event timing of one entry-point call (enabled by cat_prof_enable): records an event pair on the
+// launch stream around everything the enclosing scope enqueues, tagged with its algorithmic FLOPs / bytes.
+class ProfScope {
+ public:
+  ProfScope(const char* family, double flops, double bytes, void* stream);
+  ~ProfScope();
+
+ private:
+  bool active_;
+  void* stream_;
+  int idx_;
+};
+
 #define CAT_REQUIRE(cond, ...)            \
   do {                                    \
     if (!(cond)) {                        \

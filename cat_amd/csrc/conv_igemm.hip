@@ -557,8 +557,10 @@ int cat_conv2d_fwd(const cat_conv_t* g, const float* x, const float* w, const fl
   a.cw = g->ycw > g->Cout ? g->ycw : g->Cout;
   CAT_REQUIRE(a.cw <= g->ycs, "conv fwd: ycw > ycs");
   hipStream_t s = (hipStream_t)stream;
+  const double prof_flops = 2.0 * (double)g->N * g->Ho * g->Wo * g->Cout * g->kh * g->kw * g->Cin;
 #define LAUNCH(MT, NT, WM, WN)                                                             \
   {                                                                                        \
+    cat::ProfScope prof("conv_fwd_" #MT "x" #NT "x" #WM "x" #WN, prof_flops, 0.0, stream); \
     const int grid = cdiv(a.M, WM * MT * 16) * cdiv(a.Cout, WN * NT * 16);                 \
     conv_fwd_kernel<MT, NT, WM, WN><<<grid, 256, 0, s>>>(a);                                \
   }
@@ -581,8 +583,10 @@ int cat_conv2d_dgrad(const cat_conv_t* g, const float* dy, const float* w, const
   const int st = g->stride;
   const int mmax = g->N * cdiv(a.Hin, st) * cdiv(a.Win, st);
   hipStream_t s = (hipStream_t)stream;
+  const double prof_flops = 2.0 * (double)g->N * g->Ho * g->Wo * g->Cout * g->kh * g->kw * g->Cin;
 #define LAUNCH(MT, NT, WM, WN)                                                             \
   {                                                                                        \
+    cat::ProfScope prof("conv_dgrad_" #MT "x" #NT "x" #WM "x" #WN, prof_flops, 0.0, stream); \
     dim3 grid(cdiv(mmax, WM * MT * 16) * cdiv(a.Cin, WN * NT * 16), st * st);              \
     conv_dgrad_kernel<MT, NT, WM, WN><<<grid, 256, 0, s>>>(a);                              \
   }
@@ -611,8 +615,10 @@ int cat_conv2d_wgrad(const cat_conv_t* g, const float* x, const float* dy, float
   a.out = a.direct ? dw : (float*)ws;
   CAT_REQUIRE(a.direct || ws != nullptr, "conv wgrad: workspace required");
   hipStream_t s = (hipStream_t)stream;
+  const double prof_flops = 2.0 * (double)g->N * g->Ho * g->Wo * g->Cout * g->kh * g->kw * g->Cin;
 #define LAUNCH(MT, NT, WM, WN)                                                                         \
   {                                                                                                    \
+    cat::ProfScope prof("conv_wgrad_" #MT "x" #NT "x" #WM "x" #WN, prof_flops, 0.0, stream); \
     dim3 grid(cdiv(a.Cout, WM * MT * 16) * cdiv(a.K, WN * NT * 16), pl.nsplit);                        \
     conv_wgrad_kernel<MT, NT, WM, WN><<<grid, 256, 0, s>>>(a);                                          \
   }

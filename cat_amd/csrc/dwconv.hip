@@ -188,6 +188,7 @@ int cat_dwconv2d_fwd(const cat_conv_t* g, const float* x, const float* w, const 
   if (int e = dw_check(g)) return e;
   DwArgs a = dw_args(g);
   a.x = x; a.w = w; a.bias = bias; a.y = y;
+  cat::ProfScope prof("dwconv_fwd", 2.0 * g->N * g->Ho * g->Wo * g->Cin * g->kh * g->kw, 2 * 4.0 * (double)g->N * g->Ho * g->Wo * g->ycs, stream);
   dw_fwd_kernel<<<ew_grid((int64_t)g->N * g->Ho * g->Wo * (g->ycs / 4)), 256, 0, (hipStream_t)stream>>>(a);
   return cat::check_launch("dwconv2d_fwd");
 }
@@ -197,6 +198,7 @@ int cat_dwconv2d_dgrad(const cat_conv_t* g, const float* dy, const float* w, flo
   CAT_REQUIRE(dxcs % 4 == 0 && dxcs >= g->Cin && g->kh * g->kw * dxcs <= MAXW, "dwconv dgrad: bad dxcs");
   DwArgs a = dw_args(g);
   a.x = dy; a.xcs = g->ycs; a.w = w; a.y = dx;
+  cat::ProfScope prof("dwconv_dgrad", 2.0 * g->N * g->Ho * g->Wo * g->Cin * g->kh * g->kw, 2 * 4.0 * (double)g->N * g->Ho * g->Wo * g->ycs, stream);
   const bool refl = g->pad_mode == CAT_PAD_REFLECT;
   const int Hin = refl ? g->H + 2 * g->pad : g->H, Win = refl ? g->W + 2 * g->pad : g->W, pe = refl ? 0 : g->pad;
   dw_dgrad_kernel<<<ew_grid((int64_t)g->N * Hin * Win * (dxcs / 4)), 256, 0, (hipStream_t)stream>>>(a, Hin, Win, pe, dxcs);
@@ -214,6 +216,7 @@ int cat_dwconv2d_wgrad(const cat_conv_t* g, const float* x, const float* dy, flo
   a.x = x; a.y = const_cast<float*>(dy);
   const DwWgPlan pl = dw_wg_plan(g);
   hipStream_t s = (hipStream_t)stream;
+  cat::ProfScope prof("dwconv_wgrad", 2.0 * g->N * g->Ho * g->Wo * g->Cin * g->kh * g->kw, 2 * 4.0 * (double)g->N * g->Ho * g->Wo * g->ycs, stream);
   dim3 grid(pl.nb, g->kh);
   switch (g->kw) {
     case 1: dw_wgrad_kernel<1><<<grid, 256, 0, s>>>(a, (float*)ws, pl.nb, pl.ppl); break;

@@ -195,18 +195,21 @@ __global__ __launch_bounds__(256) void reflect_fold_kernel(const float* __restri
 extern "C" {
 
 int cat_act_fwd(const float* x, float* y, int64_t n, int act, float slope, cat_stream_t stream) {
+  cat::ProfScope prof("elementwise", 0.0, 8.0 * n, stream);
   CAT_REQUIRE(n % 4 == 0, "act_fwd: n must be a multiple of 4");
   act_fwd_kernel<<<ew_grid(n / 4), 256, 0, (hipStream_t)stream>>>(x, y, n / 4, act, slope);
   return cat::check_launch("act_fwd");
 }
 
 int cat_act_bwd(const float* y, const float* dy, float* dx, int64_t n, int act, float slope, cat_stream_t stream) {
+  cat::ProfScope prof("elementwise", 0.0, 12.0 * n, stream);
   CAT_REQUIRE(n % 4 == 0, "act_bwd: n must be a multiple of 4");
   act_bwd_kernel<<<ew_grid(n / 4), 256, 0, (hipStream_t)stream>>>(y, dy, dx, n / 4, act, slope);
   return cat::check_launch("act_bwd");
 }
 
 int cat_add_n(const float* const* srcs, int nsrc, float* dst, int64_t n, cat_stream_t stream) {
+  cat::ProfScope prof("elementwise", 0.0, 4.0 * n * (nsrc + 1), stream);
   CAT_REQUIRE(nsrc >= 1 && nsrc <= 8 && n % 4 == 0, "add_n: 1..8 sources, n multiple of 4");
   AddSrcs s{};
   for (int i = 0; i < nsrc; ++i) s.p[i] = srcs[i];
@@ -226,18 +229,21 @@ int cat_add_n(const float* const* srcs, int nsrc, float* dst, int64_t n, cat_str
 }
 
 int cat_concat2(const float* a, int ca, int acs, const float* b, int cb, int bcs, float* y, int ycs, int64_t M, cat_stream_t stream) {
+  cat::ProfScope prof("elementwise", 0.0, 8.0 * M * ycs, stream);
   CAT_REQUIRE(ca + cb <= ycs, "concat2: ycs too small");
   concat2_kernel<<<ew_grid(M * ycs), 256, 0, (hipStream_t)stream>>>(a, ca, acs, b, cb, bcs, y, ycs, M);
   return cat::check_launch("concat2");
 }
 
 int cat_slice_channels(const float* x, int xcs, int c0, int c, float* y, int ycs, int64_t M, cat_stream_t stream) {
+  cat::ProfScope prof("elementwise", 0.0, 8.0 * M * ycs, stream);
   CAT_REQUIRE(c0 + c <= xcs && c <= ycs, "slice_channels: bad range");
   slice_kernel<<<ew_grid(M * ycs), 256, 0, (hipStream_t)stream>>>(x, xcs, c0, c, y, ycs, M);
   return cat::check_launch("slice_channels");
 }
 
 int cat_nchw_to_nhwc(const float* x, float* y, int N, int C, int H, int W, int ycs, cat_stream_t stream) {
+  cat::ProfScope prof("layout", 0.0, 8.0 * N * C * H * W, stream);
   CAT_REQUIRE(ycs >= C, "nchw_to_nhwc: ycs < C");
   dim3 grid(cdiv(H * W, 64), cdiv(ycs, 64), N);
   nchw_to_nhwc_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, y, C, H * W, ycs);
@@ -245,6 +251,7 @@ int cat_nchw_to_nhwc(const float* x, float* y, int N, int C, int H, int W, int y
 }
 
 int cat_nhwc_to_nchw(const float* x, float* y, int N, int C, int H, int W, int xcs, cat_stream_t stream) {
+  cat::ProfScope prof("layout", 0.0, 8.0 * N * C * H * W, stream);
   CAT_REQUIRE(xcs >= C, "nhwc_to_nchw: xcs < C");
   dim3 grid(cdiv(H * W, 64), cdiv(C, 64), N);
   nhwc_to_nchw_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, y, C, H * W, xcs);
@@ -252,6 +259,7 @@ int cat_nhwc_to_nchw(const float* x, float* y, int N, int C, int H, int W, int x
 }
 
 int cat_fill(float* p, int64_t n, float v, cat_stream_t stream) {
+  cat::ProfScope prof("fill", 0.0, 4.0 * n, stream);
   if (n <= 0) return 0;
   fill_kernel<<<ew_grid(n), 256, 0, (hipStream_t)stream>>>(p, n, v);
   return cat::check_launch("fill");
@@ -265,6 +273,7 @@ int cat_axpy(float* y, const float* x, int64_t n, float a, cat_stream_t stream) 
 
 int cat_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                   float weight_decay, int step, float grad_scale, cat_stream_t stream) {
+  cat::ProfScope prof("adam", 0.0, 28.0 * n, stream);
   CAT_REQUIRE(step >= 1, "adam: step is 1-based");
   if (n <= 0) return 0;
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
@@ -279,6 +288,7 @@ int cat_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float
 size_t cat_channel_sum_ws_bytes(int M, int cs) { return (size_t)cs_plan(M, cs).nb * cs * sizeof(float); }
 
 int cat_channel_sum(const float* x, int M, int C, int cs, float* out, int accumulate, void* ws, cat_stream_t stream) {
+  cat::ProfScope prof("channel_sum", 0.0, 4.0 * M * cs, stream);
   CAT_REQUIRE(cs % 4 == 0 && cs >= C && ws, "channel_sum: bad arguments");
   const CsPlan p = cs_plan(M, cs);
   hipStream_t s = (hipStream_t)stream;
@@ -288,6 +298,7 @@ int cat_channel_sum(const float* x, int M, int C, int cs, float* out, int accumu
 }
 
 int cat_reflect_pad_bwd(const float* dxp, float* dx, int N, int H, int W, int C, int cs, int pad, cat_stream_t stream) {
+  cat::ProfScope prof("reflect_pad_bwd", 0.0, 8.0 * N * H * W * cs, stream);
   CAT_REQUIRE(cs % 4 == 0 && cs >= C && pad < H && pad < W, "reflect_pad_bwd: bad geometry");
   const int64_t total = (int64_t)N * H * W * (cs / 4);
   reflect_fold_kernel<<<ew_grid(total), 256, 0, (hipStream_t)stream>>>(dxp, dx, N, H, W, cs, pad);

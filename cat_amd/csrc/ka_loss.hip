@@ -247,6 +247,7 @@ int cat_ka_fwd(const float* X, int64_t Dx, const float* Y, int64_t Dy, int N, fl
   CAT_REQUIRE(N >= 1 && N <= KA_MAXN, "ka: batch N=%d outside [1,%d]", N, KA_MAXN);
   CAT_REQUIRE(Dx % 4 == 0 && Dy % 4 == 0 && ws, "ka: row lengths must be multiples of 4");
   const GramPlan px = gram_plan(N, Dx), py = gram_plan(N, Dy);
+  cat::ProfScope prof("ka_fwd", 2.0 * N * N * (double)(Dx + Dy), 4.0 * N * (double)(Dx + Dy), stream);
   float* w = (float*)ws;
   float* partx = w + 4 + 2 * N * N;
   float* party = partx + (int64_t)px.nb * px.NN * px.NN;
@@ -261,6 +262,7 @@ int cat_ka_bwd(const float* X, int64_t Dx, int N, const float* gout, const void*
   CAT_REQUIRE(N >= 1 && N <= KA_MAXN && Dx % 4 == 0, "ka bwd: bad arguments");
   int64_t nb = (Dx / 4 + 255) / 256;
   if (nb > 4096) nb = 4096;
+  cat::ProfScope prof("ka_bwd", 2.0 * N * N * (double)Dx, 8.0 * N * (double)Dx, stream);
   ka_bwd_kernel<<<(int)nb, 256, 0, (hipStream_t)stream>>>(X, Dx, N, gout, (const float*)ws, dX);
   return cat::check_launch("ka_bwd");
 }
@@ -273,6 +275,7 @@ int cat_loss_fwd(int kind, const float* a, const float* b, float target, int64_t
   CAT_REQUIRE((kind != 0 && kind != 5) || b, "loss: kind %d needs a second tensor", kind);
   const int64_t nquads = M * (cs / 4);
   const int nb = loss_nb(nquads);
+  cat::ProfScope prof("loss", 0.0, 4.0 * M * cs * (b ? 2 : 1), stream);
   hipStream_t s = (hipStream_t)stream;
   loss_partial_kernel<<<nb, 256, 0, s>>>(kind, a, b, target, nquads, cs / 4, C, (float*)ws);
   loss_final_kernel<<<1, 256, 0, s>>>((const float*)ws, nb, 1.f / (float)((double)M * C), out);
@@ -285,6 +288,7 @@ int cat_loss_bwd(int kind, const float* a, const float* b, float target, int64_t
   const int64_t nquads = M * (cs / 4);
   int64_t nb = (nquads + 255) / 256;
   if (nb > 8192) nb = 8192;
+  cat::ProfScope prof("loss", 0.0, 4.0 * M * cs * (b ? 3 : 2), stream);
   loss_bwd_kernel<<<(int)nb, 256, 0, (hipStream_t)stream>>>(kind, a, b, target, nquads, cs / 4, C, gout, scale / (float)((double)M * C), da);
   return cat::check_launch("loss_bwd");
 }

@@ -23,8 +23,9 @@ NormPlan plan(const cat_norm_t* g) {
   p.nz = cdiv(p.nq, 256);
   p.zq = cdiv(p.nq, p.nz);  // quads per z-block (<= 256)
   p.ppl = 256 / p.zq;
-  int nb = cdiv(2048, p.G * p.nz);
-  const int maxb = cdiv(p.Pg, p.ppl * 8);
+  int nb = cdiv(1024, p.G * p.nz);
+  if (nb > 256) nb = 256;
+  const int maxb = cdiv(p.Pg, p.ppl * 16);
   if (nb > maxb) nb = maxb;
   if (nb < 1) nb = 1;
   p.nb = nb;
@@ -108,20 +109,30 @@ __global__ __launch_bounds__(256) void norm_fwd_finalize_kernel(const float* __r
                                                                 float* __restrict__ running_mean, float* __restrict__ running_var,
                                                                 float* __restrict__ scale, float* __restrict__ shift, int G, int Pg,
                                                                 int C, int cs, int nb, float eps, float momentum) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= G * cs) return;
-  const int g = idx / cs, c = idx - g * cs;
+  // grid (cdiv(cs,64), G); 64 channels x 4 partial-lanes per block
+  __shared__ float red[2][256];
+  const int g = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), j = threadIdx.x >> 6;
+  float s0 = 0.f, s1 = 0.f;
+  if (c < C) {
+    for (int b = j; b < nb; b += 4) {
+      const float* src = part + ((int64_t)(g * nb + b) * 2) * cs + c;
+      s0 += src[0];
+      s1 += src[cs];
+    }
+  }
+  red[0][threadIdx.x] = s0;
+  red[1][threadIdx.x] = s1;
+  __syncthreads();
+  if (j != 0 || c >= cs) return;
+  const int idx = g * cs + c;
   if (c >= C) {
     scale[idx] = 0.f;
     shift[idx] = 0.f;
     return;
   }
-  float s0 = 0.f, s1 = 0.f;
-  for (int b = 0; b < nb; ++b) {
-    const float* src = part + ((int64_t)(g * nb + b) * 2) * cs + c;
-    s0 += src[0];
-    s1 += src[cs];
-  }
+  const int l = threadIdx.x;
+  s0 = (red[0][l] + red[0][l + 64]) + (red[0][l + 128] + red[0][l + 192]);
+  s1 = (red[1][l] + red[1][l + 64]) + (red[1][l + 128] + red[1][l + 192]);
   const float inv = 1.f / (float)Pg;
   const float d = s0 * inv;
   const float mean = x[(int64_t)g * Pg * cs + c] + d;
@@ -159,32 +170,47 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const float* __restrict
 
 __global__ __launch_bounds__(256) void norm_bwd_finalize_kernel(const float* __restrict__ part, const float* __restrict__ gamma,
                                                                 const float* __restrict__ rstd, float* __restrict__ c1,
-                                                                float* __restrict__ c2, float* __restrict__ scale,
-                                                                float* __restrict__ dgamma, float* __restrict__ dbeta, int G, int Pg,
-                                                                int C, int cs, int nb, int accumulate) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= cs) return;
-  float tg = 0.f, tb = 0.f;
-  for (int g = 0; g < G; ++g) {
-    float s0 = 0.f, s1 = 0.f;
-    if (c < C) {
-      for (int b = 0; b < nb; ++b) {
-        const float* src = part + ((int64_t)(g * nb + b) * 2) * cs + c;
-        s0 += src[0];
-        s1 += src[cs];
-      }
-    }
-    tb += s0;
-    tg += s1;
-    const float inv = 1.f / (float)Pg;
-    c1[g * cs + c] = s0 * inv;
-    c2[g * cs + c] = s1 * inv;
-    scale[g * cs + c] = c < C ? (gamma ? gamma[c] : 1.f) * rstd[g * C + c] : 0.f;
-  }
+                                                                float* __restrict__ c2, float* __restrict__ scale, int Pg, int C, int cs,
+                                                                int nb) {
+  // grid (cdiv(cs,64), G); 64 channels x 4 partial-lanes per block: per-(group, channel) means of g and g*xhat
+  __shared__ float red[2][256];
+  const int g = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), j = threadIdx.x >> 6;
+  float s0 = 0.f, s1 = 0.f;
   if (c < C) {
-    if (dgamma) dgamma[c] = accumulate ? dgamma[c] + tg : tg;
-    if (dbeta) dbeta[c] = accumulate ? dbeta[c] + tb : tb;
+    for (int b = j; b < nb; b += 4) {
+      const float* src = part + ((int64_t)(g * nb + b) * 2) * cs + c;
+      s0 += src[0];
+      s1 += src[cs];
+    }
   }
+  red[0][threadIdx.x] = s0;
+  red[1][threadIdx.x] = s1;
+  __syncthreads();
+  if (j != 0 || c >= cs) return;
+  const int l = threadIdx.x;
+  s0 = (red[0][l] + red[0][l + 64]) + (red[0][l + 128] + red[0][l + 192]);
+  s1 = (red[1][l] + red[1][l + 64]) + (red[1][l + 128] + red[1][l + 192]);
+  const float inv = 1.f / (float)Pg;
+  c1[g * cs + c] = s0 * inv;
+  c2[g * cs + c] = s1 * inv;
+  scale[g * cs + c] = c < C ? (gamma ? gamma[c] : 1.f) * rstd[g * C + c] : 0.f;
+}
+
+// dgamma[c] (+)= sum_g sum(g*xhat), dbeta[c] (+)= sum_g sum(g)  (sums recovered from the per-group means)
+__global__ __launch_bounds__(256) void norm_bwd_param_kernel(const float* __restrict__ c1, const float* __restrict__ c2,
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, int G, int Pg, int C,
+                                                             int cs, int accumulate) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float tb = 0.f, tg = 0.f;
+  for (int g = 0; g < G; ++g) {
+    tb += c1[g * cs + c];
+    tg += c2[g * cs + c];
+  }
+  tb *= (float)Pg;
+  tg *= (float)Pg;
+  if (dgamma) dgamma[c] = accumulate ? dgamma[c] + tg : tg;
+  if (dbeta) dbeta[c] = accumulate ? dbeta[c] + tb : tb;
 }
 
 // dx = gamma*rstd * (g - mean(g) - xhat * mean(g*xhat))
@@ -257,12 +283,13 @@ int cat_norm_fwd(const cat_norm_t* g, const float* x, const float* gamma, const 
                  float* save_rstd, float* running_mean, float* running_var, void* ws, cat_stream_t stream) {
   CAT_REQUIRE(g->cs % 4 == 0 && g->cs >= g->C && g->N > 0 && g->HW > 0, "norm: bad geometry");
   CAT_REQUIRE(ws && save_mean && save_rstd, "norm fwd: workspace / save buffers required");
+  cat::ProfScope prof("norm_fwd", 0.0, 3 * 4.0 * (double)g->N * g->HW * g->cs, stream);
   const NormPlan p = plan(g);
   float* w = (float*)ws;
   hipStream_t s = (hipStream_t)stream;
   norm_stats_kernel<0><<<dim3(p.nb, p.G, p.nz), 256, 0, s>>>(x, nullptr, nullptr, nullptr, nullptr, nullptr, w + p.part_off, p.Pg,
                                                               g->C, g->cs, p.zq, p.ppl, p.nb, 0, 0.f);
-  norm_fwd_finalize_kernel<<<cdiv(p.G * g->cs, 256), 256, 0, s>>>(x, w + p.part_off, gamma, beta, save_mean, save_rstd,
+  norm_fwd_finalize_kernel<<<dim3(cdiv(g->cs, 64), p.G), 256, 0, s>>>(x, w + p.part_off, gamma, beta, save_mean, save_rstd,
                                                                    g->mode == CAT_NORM_BATCH ? running_mean : nullptr,
                                                                    g->mode == CAT_NORM_BATCH ? running_var : nullptr, w + p.scale_off,
                                                                    w + p.shift_off, p.G, p.Pg, g->C, g->cs, p.nb, g->eps, g->momentum);
@@ -276,13 +303,16 @@ int cat_norm_bwd(const cat_norm_t* g, const float* x, const float* dy, const flo
                  const float* save_rstd, float* dx, float* dgamma, float* dbeta, int accumulate, void* ws, cat_stream_t stream) {
   CAT_REQUIRE(g->cs % 4 == 0 && g->cs >= g->C && g->N > 0 && g->HW > 0, "norm: bad geometry");
   CAT_REQUIRE(ws, "norm bwd: workspace required");
+  cat::ProfScope prof("norm_bwd", 0.0, 5 * 4.0 * (double)g->N * g->HW * g->cs, stream);
   const NormPlan p = plan(g);
   float* w = (float*)ws;
   hipStream_t s = (hipStream_t)stream;
   norm_stats_kernel<1><<<dim3(p.nb, p.G, p.nz), 256, 0, s>>>(x, dy, gamma, beta, save_mean, save_rstd, w + p.part_off, p.Pg, g->C, g->cs,
                                                               p.zq, p.ppl, p.nb, g->act, g->slope);
-  norm_bwd_finalize_kernel<<<cdiv(g->cs, 256), 256, 0, s>>>(w + p.part_off, gamma, save_rstd, w + p.c1_off, w + p.c2_off, w + p.scale_off,
-                                                             dgamma, dbeta, p.G, p.Pg, g->C, g->cs, p.nb, accumulate);
+  norm_bwd_finalize_kernel<<<dim3(cdiv(g->cs, 64), p.G), 256, 0, s>>>(w + p.part_off, gamma, save_rstd, w + p.c1_off, w + p.c2_off,
+                                                                        w + p.scale_off, p.Pg, g->C, g->cs, p.nb);
+  if (dgamma || dbeta)
+    norm_bwd_param_kernel<<<cdiv(g->C, 256), 256, 0, s>>>(w + p.c1_off, w + p.c2_off, dgamma, dbeta, p.G, p.Pg, g->C, g->cs, accumulate);
   const int64_t nquads = (int64_t)g->N * g->HW * p.nq;
   norm_bwd_apply_kernel<<<ew_grid(nquads), 256, 0, s>>>(x, dy, gamma, beta, save_mean, save_rstd, w + p.c1_off, w + p.c2_off,
                                                          w + p.scale_off, dx, nquads, p.nq, (int64_t)p.Pg * p.nq, g->C, g->cs, g->act,
@@ -300,6 +330,7 @@ int cat_affine_act_fwd(const float* x, const float* scale, const float* shift, f
                        cat_stream_t stream) {
   CAT_REQUIRE(cs % 4 == 0 && cs >= C, "affine_act: bad channel stride");
   const int64_t nquads = M * (cs / 4);
+  cat::ProfScope prof("affine_act", 0.0, 8.0 * M * cs, stream);
   affine_act_kernel<<<ew_grid(nquads), 256, 0, (hipStream_t)stream>>>(x, scale, shift, y, nquads, cs / 4, C, act, slope);
   return cat::check_launch("affine_act");
 }

@@ -95,6 +95,8 @@ class InceptionDistiller(BaseInceptionDistiller):
         torch.autograd.backward(terms, seeds)
 
     def optimize_parameters(self, steps):
+        if self.dp is not None and getattr(self, 'dp_overlap', True):
+            return self._optimize_parameters_overlapped(steps)
         self.forward()
         self.set_requires_grad(self.netD, True)
         self.optimizer_D.zero_grad()
@@ -108,3 +110,45 @@ class InceptionDistiller(BaseInceptionDistiller):
         if self.dp is not None:
             self.dp.reduce(self.optimizer_G)
         self.optimizer_G.step()
+
+    # -- data-parallel schedule ---------------------------------------------------------------------------------
+    def enable_data_parallel(self, reducer, overlap=True):
+        """Attach a cat_amd.parallel.DataParallelReducer: replicas are synchronised once, then only gradients move."""
+        self.dp = reducer
+        self.dp_overlap = overlap
+        self._pending_G = None
+        self._side_stream = torch.cuda.Stream(device=self.device)
+        reducer.broadcast_parameters([self.netG_teacher, self.netG_student, self.netD] + list(self.netAs))
+
+    def finish_pending(self):
+        """Complete a deferred student update (all-reduce wait + Adam G).  Called before anything reads the weights."""
+        if getattr(self, '_pending_G', None) is not None:
+            self._pending_G.wait()
+            self.optimizer_G.step()
+            self._pending_G = None
+
+    def _optimize_parameters_overlapped(self, steps):
+        """Same arithmetic as optimize_parameters, scheduled for xGMI overlap:
+          side stream : frozen-teacher forward of THIS batch
+          main stream : [wait G all-reduce of the previous step -> Adam G] -> student forward -> D step (D bucket
+                        all-reduce, Adam D) -> backward_G -> launch G bucket all-reduce (awaited next call)."""
+        main = torch.cuda.current_stream(self.device)
+        side = self._side_stream
+        side.wait_stream(main)
+        with torch.cuda.stream(side), torch.no_grad():
+            self.Tfake_B = self.netG_teacher(self.real_A)
+        t_done = side.record_event()
+        self.finish_pending()
+        self.Sfake_B = self.netG_student(self.real_A)
+        self.set_requires_grad(self.netD, True)
+        self.optimizer_D.zero_grad()
+        self.backward_D()
+        self.dp.reduce(self.optimizer_D)
+        self.optimizer_D.step()
+        self.set_requires_grad(self.netD, False)
+        self.optimizer_G.zero_grad()
+        main.wait_event(t_done)
+        for t in [self.Tfake_B] + list(self.Tacts.values()):
+            t.record_stream(main)
+        self.backward_G(steps)
+        self._pending_G = self.dp.reduce_async(self.optimizer_G)

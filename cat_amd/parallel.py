@@ -1,0 +1,95 @@
+"""Data parallelism for the distillation step: one process per GPU, gradients exchanged with RCCL over xGMI.
+
+The reference uses single-process nn.DataParallel (models/networks.py:157-161): scatter the batch, replicate the
+module, gather outputs to GPU 0, compute the losses there.  Here every rank owns a full replica and its shard of the
+batch (same contiguous chunking as DataParallel.scatter), and only gradients cross the fabric:
+
+  * the buckets are the FusedAdam flat gradient buffers themselves (one per optimizer param group: D ~ 11-44 MB,
+    student 2-4 MB, netAs ~0.3 MB) -- no bucket copies, one ring all-reduce per bucket;
+  * D bucket: reduced right after backward_D (Adam D needs it before backward_G reads the updated D);
+  * G bucket: launched asynchronously on RCCL's stream; its completion is only awaited where the student's updated
+    weights are needed (the next student forward), so it overlaps the next iteration's frozen-teacher forward, which
+    runs on a side HIP stream and depends on no trainable state;
+  * loss semantics of DataParallel are reproduced with gradient AVERAGING (sum all-reduce, 1/world_size
+    folded into the Adam kernel) plus a world_size factor on the per-shard KA seed (inception_distiller.py:136-148
+    sums per-device KA terms).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(backend=None):
+    """Initialise torch.distributed from the torchrun environment (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*).
+    backend 'nccl' is RCCL on ROCm; 'gloo' is used by the CPU tests."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world <= 1:
+        return 0, 1, 0
+    rank = int(os.environ['RANK'])
+    local = int(os.environ.get('LOCAL_RANK', rank))
+    if backend is None:
+        backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+    if backend == 'nccl':
+        torch.cuda.set_device(local)
+    if not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        kw = {}
+        if backend == 'nccl':
+            kw['device_id'] = torch.device('cuda', local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+    return rank, world, local
+
+
+def shard_batch(batch, rank, world_size):
+    """The chunk DataParallel.scatter would hand replica `rank` (contiguous split of dim 0, torch.chunk semantics)."""
+    out = {}
+    for k, v in batch.items():
+        out[k] = v.chunk(world_size, 0)[rank] if torch.is_tensor(v) else v
+    return out
+
+
+class PendingReduce:
+    def __init__(self, works, optimizer, world_size):
+        self.works, self.optimizer, self.world_size = works, optimizer, world_size
+
+    def wait(self):
+        """Make the CURRENT stream wait for the collective (no host sync for NCCL/RCCL works)."""
+        for w in self.works:
+            w.wait()
+        self.works = []
+
+
+class DataParallelReducer:
+    def __init__(self, group=None):
+        if not dist.is_initialized():
+            raise RuntimeError('torch.distributed is not initialised (launch with torchrun / init_distributed())')
+        self.group = group
+        self.world_size = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+
+    def _buckets(self, optimizer_or_tensors):
+        if hasattr(optimizer_or_tensors, 'flat_grads'):
+            return optimizer_or_tensors.flat_grads()
+        return list(optimizer_or_tensors)
+
+    def reduce_async(self, optimizer_or_tensors):
+        """Sum-all-reduce every gradient bucket; the 1/world_size average is applied by the optimizer kernel."""
+        works = [dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group, async_op=True) for b in self._buckets(optimizer_or_tensors)]
+        if hasattr(optimizer_or_tensors, 'grad_scale'):
+            optimizer_or_tensors.grad_scale = 1.0 / self.world_size
+        return PendingReduce(works, optimizer_or_tensors, self.world_size)
+
+    def reduce(self, optimizer_or_tensors):
+        self.reduce_async(optimizer_or_tensors).wait()
+
+    def broadcast_parameters(self, modules, src=0):
+        """Replicas start identical (DataParallel replicates GPU 0's module every forward)."""
+        for m in modules:
+            for t in list(m.parameters()) + list(m.buffers()):
+                dist.broadcast(t.data, src=src, group=self.group)
+
+    def max_over_ranks(self, seconds):
+        t = torch.tensor([seconds], dtype=torch.float64, device='cuda' if dist.get_backend(self.group) == 'nccl' else 'cpu')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return float(t.item())

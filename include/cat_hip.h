@@ -143,6 +143,14 @@ int cat_loss_bwd(int kind, const float* a, const float* b, float target, int64_t
  * p, g, m, v: n floats; step = 1-based step count. */
 int cat_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                   float eps, float weight_decay, int step, float grad_scale, cat_stream_t stream);
+/* Measurement hook (bench.py `roofline`): while enabled, every entry point brackets what it enqueues with a HIP event
+ * pair on the caller's stream, tagged with a kernel-family name and its algorithmic FLOPs.  cat_prof_collect()
+ * synchronises and folds the records per family; cat_prof_family(i, ...) reads family i (count, total ms, total FLOPs). */
+void cat_prof_enable(int on);
+int cat_prof_collect(void);
+int cat_prof_family(int i, char* name, int cap, int64_t* count, double* ms, double* flops);
+double cat_prof_family_bytes(int i);
+
 int cat_fill(float* p, int64_t n, float v, cat_stream_t stream);
 int cat_axpy(float* y, const float* x, int64_t n, float a, cat_stream_t stream); /* y += a*x */
 
