@@ -382,6 +382,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(IgemmArgs p) {
     acv[i] = apix[i] < 16 && c0 + acq[i] * 4 < cout4;
   }
 
+  // (n, oy, ox) of the pixel each B' lane gathers; advanced by 16 pixels per chunk without divisions
+  int pn[BI], poy[BI], pox[BI];
+#pragma unroll
+  for (int i = 0; i < BI; ++i) {
+    const int m = min(mbeg + bpix[i], p.M - 1);
+    pn[i] = m / HoWo;
+    const int rem = m - pn[i] * HoWo;
+    poy[i] = rem / p.Wo;
+    pox[i] = rem - poy[i] * p.Wo;
+  }
+  // NB: gload must be called with kc = 0, 1, 2, ... exactly once each, in order
   f4 ra[AI], rb[BI];
   auto gload = [&](int kc) {
     const int mb = mbeg + kc * 16;
@@ -394,9 +405,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(IgemmArgs p) {
     for (int i = 0; i < BI; ++i) {
       const int m = mb + bpix[i];
       bool v = bcv[i] && m < mend;
-      const int mm = v ? m : 0;
-      const int n = mm / HoWo, rem = mm - n * HoWo;
-      const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+      const int n = pn[i], oy = poy[i], ox = pox[i];
+      pox[i] += 16;
+      while (pox[i] >= p.Wo) {
+        pox[i] -= p.Wo;
+        if (++poy[i] >= p.Ho) {
+          poy[i] = 0;
+          ++pn[i];
+        }
+      }
       int iy = oy * p.stride - p.pad + bky[i], ix = ox * p.stride - p.pad + bkx[i];
       if (p.reflect) {
         iy = cat::reflect_idx(iy, p.H);
@@ -467,7 +484,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(IgemmArgs p) {
         const int co = c0 + wm * MT * 16 + i * 16 + lq * 4 + rg;
         if (co >= p.Cout) continue;
         if (p.direct) {
-          if (ci < p.Cin) p.out[((int64_t)co * taps + tap) * p.Cin + ci] = acc[i][j][rg];
+          if (ci < p.Cin) {
+            float* dst = p.out + ((int64_t)co * taps + tap) * p.Cin + ci;
+            *dst = p.accumulate ? *dst + acc[i][j][rg] : acc[i][j][rg];
+          }
         } else {
           p.out[((int64_t)blockIdx.y * p.Cout + co) * p.K + k] = acc[i][j][rg];
         }
@@ -476,17 +496,26 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(IgemmArgs p) {
   }
 }
 
-// dw[co][tap][ci] (+)= sum_z ws[z][co][tap*c4 + ci]
+// dw[co][tap][ci] (+)= sum_z ws[z][co][tap*c4 + ci]; 64 outputs x 4 split-lanes per workgroup (coalesced in ci)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nsplit,
                                                            int Cout, int taps, int Cin, int c4, int K, int accumulate) {
+  __shared__ float red[256];
   const int64_t total = (int64_t)Cout * taps * Cin;
-  for (int64_t e = blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+  const int64_t e = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
+  const int zl = threadIdx.x >> 6;
+  float s = 0.f;
+  if (e < total) {
     const int ci = (int)(e % Cin);
     const int64_t ct = e / Cin;
     const int tap = (int)(ct % taps), co = (int)(ct / taps);
     const float* src = ws + (int64_t)co * K + tap * c4 + ci;
-    float s = 0.f;
-    for (int z = 0; z < nsplit; ++z) s += src[(int64_t)z * Cout * K];
+    for (int z = zl; z < nsplit; z += 4) s += src[(int64_t)z * Cout * K];
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (zl == 0 && e < total) {
+    const int l = threadIdx.x;
+    s = (red[l] + red[l + 64]) + (red[l + 128] + red[l + 192]);
     dw[e] = accumulate ? dw[e] + s : s;
   }
 }
@@ -536,7 +565,8 @@ WgradPlan wgrad_plan(const cat_conv_t* g) {
   pl.tiles = cdiv(Cout, BM) * cdiv(K, BN);
   const int M = g->N * g->Ho * g->Wo;
   int ns = cdiv(1024, pl.tiles);
-  const int maxs = M / 256 > 0 ? M / 256 : 1;
+  int maxs = M / 256 > 0 ? M / 256 : 1;
+  if (maxs > 256) maxs = 256;
   if (ns > maxs) ns = maxs;
   if (ns < 1) ns = 1;
   pl.mchunk = cat::round_up(cdiv(M, ns), 16);
@@ -610,7 +640,7 @@ int cat_conv2d_wgrad(const cat_conv_t* g, const float* x, const float* dy, float
   a.c4 = (g->Cin + 3) & ~3;
   a.K = g->kh * g->kw * a.c4;
   a.nsplit = pl.nsplit; a.mchunk = pl.mchunk;
-  a.direct = (pl.nsplit == 1 && !accumulate) ? 1 : 0;
+  a.direct = pl.nsplit == 1 ? 1 : 0;
   a.accumulate = accumulate;
   a.out = a.direct ? dw : (float*)ws;
   CAT_REQUIRE(a.direct || ws != nullptr, "conv wgrad: workspace required");
@@ -632,7 +662,7 @@ int cat_conv2d_wgrad(const cat_conv_t* g, const float* x, const float* dy, float
   if (int e = cat::check_launch("conv2d_wgrad")) return e;
   if (!a.direct) {
     const int64_t total = (int64_t)a.Cout * a.kh * a.kw * a.Cin;
-    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    const int grid = (int)((total + 63) / 64);
     wgrad_reduce_kernel<<<grid, 256, 0, s>>>((const float*)ws, dw, pl.nsplit, a.Cout, a.kh * a.kw, a.Cin, a.c4, a.K, accumulate);
     return cat::check_launch("conv2d_wgrad_reduce");
   }

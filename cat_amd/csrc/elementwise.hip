@@ -140,12 +140,20 @@ __global__ __launch_bounds__(256) void chansum_partial_kernel(const float* __res
     *reinterpret_cast<f4*>(part + (int64_t)b * cs + cq * 4) = s;
   }
 }
-__global__ void chansum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int C, int cs, int nb, int accumulate) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
+__global__ __launch_bounds__(256) void chansum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int C, int cs, int nb,
+                                                            int accumulate) {
+  __shared__ float red[256];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), zl = threadIdx.x >> 6;
   float s = 0.f;
-  for (int b = 0; b < nb; ++b) s += part[(int64_t)b * cs + c];
-  out[c] = accumulate ? out[c] + s : s;
+  if (c < C)
+    for (int b = zl; b < nb; b += 4) s += part[(int64_t)b * cs + c];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (zl == 0 && c < C) {
+    const int l = threadIdx.x;
+    s = (red[l] + red[l + 64]) + (red[l + 128] + red[l + 192]);
+    out[c] = accumulate ? out[c] + s : s;
+  }
 }
 
 struct CsPlan { int nq, nz, zq, ppl, nb; };
@@ -155,8 +163,8 @@ CsPlan cs_plan(int64_t M, int cs) {
   p.nz = cdiv(p.nq, 256);
   p.zq = cdiv(p.nq, p.nz);
   p.ppl = 256 / p.zq;
-  int nb = cdiv(1024, p.nz);
-  const int maxb = cdiv(M, (int64_t)p.ppl * 8);
+  int nb = cdiv(512, p.nz);
+  const int maxb = cdiv(M, (int64_t)p.ppl * 16);
   if (nb > maxb) nb = maxb;
   if (nb < 1) nb = 1;
   p.nb = nb;
@@ -293,7 +301,7 @@ int cat_channel_sum(const float* x, int M, int C, int cs, float* out, int accumu
   const CsPlan p = cs_plan(M, cs);
   hipStream_t s = (hipStream_t)stream;
   chansum_partial_kernel<<<dim3(p.nb, p.nz), 256, 0, s>>>(x, (float*)ws, M, cs, p.zq, p.ppl, p.nb);
-  chansum_final_kernel<<<cdiv(C, 256), 256, 0, s>>>((const float*)ws, out, C, cs, p.nb, accumulate);
+  chansum_final_kernel<<<cdiv(C, 64), 256, 0, s>>>((const float*)ws, out, C, cs, p.nb, accumulate);
   return cat::check_launch("channel_sum");
 }
 

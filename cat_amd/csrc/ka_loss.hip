@@ -67,20 +67,38 @@ __global__ __launch_bounds__(256) void gram_kernel(const float* __restrict__ X, 
 }
 
 // ws layout (floats): [0..3] sxy, sxx, syy, ka | Gx[N*N] | Gy[N*N] | partX[nb][NN*NN] | partY[nb][NN*NN]
-__global__ __launch_bounds__(256) void ka_finalize_kernel(float* __restrict__ ws, int N, int NN, int nbx, int nby, float* __restrict__ out) {
-  __shared__ float red[3][256];
+// stage 1: Gx / Gy entries = sum of the per-workgroup partials; 64 entries x 4 partial-lanes per workgroup
+__global__ __launch_bounds__(256) void ka_gram_reduce_kernel(float* __restrict__ ws, int N, int NN, int nbx, int nby) {
+  __shared__ float red[2][256];
   float* Gx = ws + 4;
   float* Gy = Gx + N * N;
   const float* px = Gy + N * N;
   const float* py = px + (int64_t)nbx * NN * NN;
+  const int e = blockIdx.x * 64 + (threadIdx.x & 63), zl = threadIdx.x >> 6;
+  float gx = 0.f, gy = 0.f;
+  if (e < N * N) {
+    const int i = e / N, j = e - i * N;
+    for (int b = zl; b < nbx; b += 4) gx += px[(int64_t)b * NN * NN + i * NN + j];
+    for (int b = zl; b < nby; b += 4) gy += py[(int64_t)b * NN * NN + i * NN + j];
+  }
+  red[0][threadIdx.x] = gx;
+  red[1][threadIdx.x] = gy;
+  __syncthreads();
+  if (zl == 0 && e < N * N) {
+    const int l = threadIdx.x;
+    Gx[e] = (red[0][l] + red[0][l + 64]) + (red[0][l + 128] + red[0][l + 192]);
+    Gy[e] = (red[1][l] + red[1][l + 64]) + (red[1][l + 128] + red[1][l + 192]);
+  }
+}
+
+// stage 2: ws[0..3] = sxy, sxx, syy, ka
+__global__ __launch_bounds__(256) void ka_finalize_kernel(float* __restrict__ ws, int N, float* __restrict__ out) {
+  __shared__ float red[3][256];
+  const float* Gx = ws + 4;
+  const float* Gy = Gx + N * N;
   float sxy = 0.f, sxx = 0.f, syy = 0.f;
   for (int e = threadIdx.x; e < N * N; e += 256) {
-    const int i = e / N, j = e - i * N;
-    float gx = 0.f, gy = 0.f;
-    for (int b = 0; b < nbx; ++b) gx += px[(int64_t)b * NN * NN + i * NN + j];
-    for (int b = 0; b < nby; ++b) gy += py[(int64_t)b * NN * NN + i * NN + j];
-    Gx[e] = gx;
-    Gy[e] = gy;
+    const float gx = Gx[e], gy = Gy[e];
     sxy += gx * gy;
     sxx += gx * gx;
     syy += gy * gy;
@@ -254,7 +272,8 @@ int cat_ka_fwd(const float* X, int64_t Dx, const float* Y, int64_t Dy, int N, fl
   hipStream_t s = (hipStream_t)stream;
   if (int e = launch_gram(X, Dx, N, partx, px, s)) return e;
   if (int e = launch_gram(Y, Dy, N, party, py, s)) return e;
-  ka_finalize_kernel<<<1, 256, 0, s>>>(w, N, px.NN, px.nb, py.nb, out);
+  ka_gram_reduce_kernel<<<cdiv(N * N, 64), 256, 0, s>>>(w, N, px.NN, px.nb, py.nb);
+  ka_finalize_kernel<<<1, 256, 0, s>>>(w, N, out);
   return cat::check_launch("ka_finalize");
 }
 
