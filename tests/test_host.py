@@ -1,0 +1,72 @@
+"""CPU: host-side logic of the drop-in boundary -- state_dict key / shape parity with the reference networks, the
+distiller factory and flag surface, fused-Sequential structure, loud failure without a GPU."""
+import argparse
+
+import pytest
+import torch
+
+import helpers as H
+
+
+@pytest.mark.parametrize('tag,norm,track', [('in', 'instance', False), ('bn', 'batch', True)])
+def test_state_dict_keys_match_reference(tag, norm, track):
+    """tests/golden/forward_*.npz records the reference student's state_dict (keys, shapes) after shrink_model."""
+    g = H.load(f'forward_{tag}.npz')
+    shapes = H.sd_from_shapes(g['student_shapes'])
+    opt = H.make_opt(norm=norm, track=track)
+    net = H.student_from_shapes(opt, shapes)
+    assert list(net.state_dict().keys()) == list(shapes.keys())
+    from cat_amd import networks
+    T = networks.define_G(3, 3, 64, 'inception_9blocks', norm, 0, 'normal', 0.02, [], opt=opt)
+    tsd = T.state_dict()
+    if track:   # BatchNorm: no conv bias in front of a norm (inception_generator.py:30-33), 95 norm layers with running stats
+        assert 'down_sampling.1.bias' not in tsd and sum(k.endswith('running_var') for k in tsd) == 95
+    else:
+        assert len(tsd) == 472
+    D = networks.define_D(6, 128, 'n_layers', 3, norm, 'normal', 0.02, [], opt=opt)
+    assert [k for k in D.state_dict() if k.endswith('weight')][:2] == ['model.0.weight', 'model.2.weight']
+    assert D.model[0].bias is not None and (D.model[2].bias is None) == (norm == 'batch')
+
+
+def test_weights_are_channels_last_after_flatten_rules():
+    from cat_amd import nn as cnn
+    c = cnn.Conv2d(8, 4, 3)
+    cnn._to_channels_last_(c)
+    assert c.weight.permute(0, 2, 3, 1).is_contiguous()
+    sd = c.state_dict()
+    assert sd['weight'].shape == (4, 8, 3, 3)          # logical OIHW is the checkpoint format
+
+
+def test_factory_and_flags():
+    from cat_amd.distillers import find_distiller_using_name, get_option_setter
+    cls = find_distiller_using_name('inception')
+    assert cls.__name__ == 'InceptionDistiller'
+    p = argparse.ArgumentParser()
+    for flag in ('--norm', '--dataset_mode', '--log_dir'):
+        p.add_argument(flag, default=None)
+    get_option_setter('inception')(p, True)
+    o = p.parse_args([])
+    assert o.teacher_ngf == 64 and o.student_ngf == 48 and o.lambda_recon == 100 and o.distill_G_loss_type == 'mse'
+    assert o.norm == 'instance' and o.dataset_mode == 'aligned' and o.pretrained_ngf == 64 and o.target_flops == 0
+    with pytest.raises(NotImplementedError):
+        find_distiller_using_name('spade')
+
+
+def test_no_cpu_fallback():
+    from cat_amd import ops
+    from cat_amd import networks
+    opt = H.make_opt()
+    net = networks.define_G(3, 3, 16, 'inception_9blocks', 'instance', 0, 'normal', 0.02, [], opt=opt)
+    with pytest.raises(RuntimeError, match='GPU only'):
+        net(torch.zeros(1, 3, 32, 32))
+    if not torch.cuda.is_available():
+        from cat_amd.distillers import create_distiller
+        with pytest.raises(RuntimeError, match='MI355X'):
+            create_distiller(opt, verbose=False)
+
+
+def test_loss_value_arithmetic():
+    from cat_amd.distillers.base_inception_distiller import LossValue
+    a, b = torch.tensor(2.0), torch.tensor(3.0)
+    v = LossValue([(0.5, a), (0.5, b)])
+    assert float(v) == 2.5 and float(v * 2) == 5.0 and float(v + LossValue([(1.0, a)]) + 0) == 4.5
