@@ -33,6 +33,12 @@ class ProfScope {
     }                                     \
   } while (0)
 
+// Cout <= 4 direct convolutions (conv_smallco.hip)
+bool smallco_applicable(const cat_conv_t* g);
+int smallco_fwd(const cat_conv_t* g, const float* x, const float* w, const float* bias, float* y, hipStream_t s);
+int smallco_wgrad_nblk(const cat_conv_t* g);
+int smallco_wgrad(const cat_conv_t* g, const float* x, const float* dy, float* ws, hipStream_t s);
+
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 

@@ -587,6 +587,10 @@ int cat_conv2d_fwd(const cat_conv_t* g, const float* x, const float* w, const fl
   a.cw = g->ycw > g->Cout ? g->ycw : g->Cout;
   CAT_REQUIRE(a.cw <= g->ycs, "conv fwd: ycw > ycs");
   hipStream_t s = (hipStream_t)stream;
+  if (cat::smallco_applicable(g)) {
+    cat::ProfScope prof("conv_fwd_smallco", 2.0 * (double)g->N * g->Ho * g->Wo * g->Cout * g->kh * g->kw * g->Cin, 0.0, stream);
+    return cat::smallco_fwd(g, x, w, bias, y, s);
+  }
   const double prof_flops = 2.0 * (double)g->N * g->Ho * g->Wo * g->Cout * g->kh * g->kw * g->Cin;
 #define LAUNCH(MT, NT, WM, WN)                                                             \
   {                                                                                        \
@@ -628,6 +632,7 @@ int cat_conv2d_dgrad(const cat_conv_t* g, const float* dy, const float* w, const
 size_t cat_conv2d_wgrad_ws_bytes(const cat_conv_t* g) {
   const WgradPlan pl = wgrad_plan(g);
   const size_t K = (size_t)g->kh * g->kw * ((g->Cin + 3) & ~3);
+  if (cat::smallco_applicable(g)) return (size_t)cat::smallco_wgrad_nblk(g) * g->Cout * K * sizeof(float);
   return (size_t)pl.nsplit * g->Cout * K * sizeof(float);
 }
 
@@ -643,8 +648,18 @@ int cat_conv2d_wgrad(const cat_conv_t* g, const float* x, const float* dy, float
   a.direct = pl.nsplit == 1 ? 1 : 0;
   a.accumulate = accumulate;
   a.out = a.direct ? dw : (float*)ws;
-  CAT_REQUIRE(a.direct || ws != nullptr, "conv wgrad: workspace required");
   hipStream_t s = (hipStream_t)stream;
+  if (cat::smallco_applicable(g)) {
+    CAT_REQUIRE(ws != nullptr, "conv wgrad: workspace required");
+    const double fl = 2.0 * (double)g->N * g->Ho * g->Wo * g->Cout * g->kh * g->kw * g->Cin;
+    cat::ProfScope prof("conv_wgrad_smallco", fl, 0.0, stream);
+    if (int e = cat::smallco_wgrad(g, x, dy, (float*)ws, s)) return e;
+    const int64_t total = (int64_t)a.Cout * a.kh * a.kw * a.Cin;
+    wgrad_reduce_kernel<<<(int)((total + 63) / 64), 256, 0, s>>>((const float*)ws, dw, cat::smallco_wgrad_nblk(g), a.Cout, a.kh * a.kw,
+                                                                  a.Cin, a.c4, a.K, accumulate);
+    return cat::check_launch("conv2d_wgrad_reduce");
+  }
+  CAT_REQUIRE(a.direct || ws != nullptr, "conv wgrad: workspace required");
   const double prof_flops = 2.0 * (double)g->N * g->Ho * g->Wo * g->Cout * g->kh * g->kw * g->Cin;
 #define LAUNCH(MT, NT, WM, WN)                                                                         \
   {                                                                                                    \
