@@ -15,7 +15,7 @@ c_p = C.c_void_p
 
 class ConvGeom(C.Structure):
     _fields_ = [(n, c_i) for n in ('N', 'H', 'W', 'Cin', 'xcs', 'Ho', 'Wo', 'Cout', 'ycs', 'kh', 'kw', 'stride', 'pad',
-                                   'pad_mode', 'act')] + [('slope', c_f), ('ycw', c_i)]
+                                   'pad_mode', 'act')] + [('slope', c_f), ('ycw', c_i), ('wcs', c_i)]
 
 
 class NormGeom(C.Structure):

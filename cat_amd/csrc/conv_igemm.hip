@@ -15,6 +15,7 @@
 // Ragged channel counts (pruned students: 4..17, 56, 82 ...) never touch HBM layout beyond the 4-float pixel
 // stride: the N edge is handled by 16-wide tile variants chosen per layer, the K edge by zero-filled quads.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -31,19 +32,36 @@ struct IgemmArgs {
   int act;
   float slope;
   int cw;        // channels [Cvalid, cw) of the output pixel get zeros
-  int c4;        // per-tap K extent (cin4 for fwd/wgrad, cout4 for dgrad)
+  int c4;        // per-tap K extent of the walk (fwd/dgrad: may be rounded up to 16 so that a chunk never straddles taps)
+  int cval;      // channels that may actually be read per pixel (round_up(C, 4)); quads beyond it come from the zero page
   int K;         // fwd/wgrad: kh*kw*cin4
   int M;         // fwd/wgrad: N*Ho*Wo
   int wvec;      // weight rows can be read as float4
+  int wcs;       // weight floats per (cout, tap)
   // dgrad
   int Hin, Win, pad_eff, ocs;
   // wgrad
   int nsplit, mchunk, direct, accumulate;
+  int ablate;  // diagnostics only
+  long long* dbg;  // diagnostics only (CAT_DBG): per-phase shader-clock totals of one wave
 };
 
 __device__ __forceinline__ int swz(int r, int q) { return (r * 4 + (q ^ ((r >> 1) & 3))) * 4; }
 
 __device__ __forceinline__ f4 ldg4(const float* p) { return *reinterpret_cast<const f4*>(p); }
+
+// Out-of-range / padding elements are read from this zero page instead of being branched around: every lane always
+// issues its load, so the compiler can count outstanding loads (s_waitcnt vmcnt(N)) and keep a whole chunk in flight.
+// (`v ? load : 0` compiles to exec-masked branches with a vmcnt(0) behind each load: fully serialised latency.)
+__device__ __attribute__((aligned(16))) float g_zero_page[4] = {0.f, 0.f, 0.f, 0.f};  // global (not constant) address space: keeps loads global_load
+__device__ __forceinline__ f4 ldg4_or_zero(bool valid, const float* p) { return ldg4(valid ? p : g_zero_page); }
+__device__ __forceinline__ f4 ldw4_or_zero(bool valid, bool vec, const float* wp, int ci, int cin) {
+  if (vec) return ldg4(valid ? wp : g_zero_page);
+  f4 v;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = *((valid && ci + e < cin) ? wp + e : g_zero_page);
+  return v;
+}
 
 template <int MT, int NT>
 __device__ __forceinline__ void mma_kcontig_a_kcontig_b(const float* A, const float* B, int arow0, int brow0, int lane,
@@ -63,7 +81,7 @@ __device__ __forceinline__ void mma_kcontig_a_kcontig_b(const float* A, const fl
 }
 
 // ------------------------------------------------------------------------------------------------ forward
-template <int MT, int NT, int WM, int WN>
+template <int MT, int NT, int WM, int WN, bool WVEC = false, int SCHED = 0>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(IgemmArgs p) {
   constexpr int BM = WM * MT * 16, BN = WN * NT * 16;
   constexpr int AI = BM / 64, BI = (BN + 63) / 64;
@@ -99,41 +117,77 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(IgemmArgs p) {
   for (int i = 0; i < BI; ++i) {
     const int r = r0 + 64 * i, co = n0 + r;
     bv[i] = r < BN && co < p.Cout;
-    wrow[i] = p.b + (int64_t)(bv[i] ? co : 0) * taps * p.Cin;
+    wrow[i] = p.b + (int64_t)(bv[i] ? co : 0) * taps * p.wcs;
   }
 
-  f4 ra[AI], rb[BI];
-  auto gload = [&](int kc) {
-    const int k = kc * 16 + q * 4;
-    const bool kv = k < p.K;
-    const int tap = kv ? k / p.c4 : 0, ci = kv ? k - tap * p.c4 : 0;
-    const int ky = tap / p.kw, kx = tap - ky * p.kw;
+  // K walk of this thread's quad: k = kc*16 + q*4 = (tap, ci).  The walk is INCREMENTAL -- on gfx950 the fp32 MFMA runs at the
+  // fp32 VALU rate on shared issue slots, so every vector instruction in this loop is paid in matrix throughput (measured:
+  // 64 MFMA + ~250 VALU per chunk = 65 % of peak).  Steady state costs two pointer bumps per operand; only lanes whose quad
+  // crosses a tap boundary take the (divergent, rare for wide layers) re-location branch.
+  const bool aligned = (p.c4 & 15) == 0;
+  int k = q * 4, ci, ky, kx;
+  {
+    const int tap = k / p.c4;
+    ci = k - tap * p.c4;
+    ky = tap / p.kw;
+    kx = tap - ky * p.kw;
+  }
+  const float* pa[AI];
+  bool va[AI];
+  const float* pb[BI];
+  auto locate = [&]() {
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
       int iy = iy0[i] + ky, ix = ix0[i] + kx;
-      bool v = rv[i] && kv;
-      if (p.reflect) {
-        iy = cat::reflect_idx(iy, p.H);
-        ix = cat::reflect_idx(ix, p.W);
-      } else {
-        v = v && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-      }
-      ra[i] = v ? ldg4(p.a + xoff[i] + ((int64_t)iy * p.W + ix) * p.xcs + ci) : f4{0.f, 0.f, 0.f, 0.f};
+      const bool inr = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      const int ry = cat::reflect_idx(iy, p.H), rx = cat::reflect_idx(ix, p.W);
+      iy = p.reflect ? ry : (inr ? iy : 0);
+      ix = p.reflect ? rx : (inr ? ix : 0);
+      va[i] = rv[i] && (p.reflect || inr);
+      pa[i] = p.a + xoff[i] + ((int64_t)iy * p.W + ix) * p.xcs + ci;
     }
+  };
+  locate();
 #pragma unroll
-    for (int i = 0; i < BI; ++i) {
-      const float* wp = wrow[i] + (int64_t)tap * p.Cin + ci;
-      f4 v = {0.f, 0.f, 0.f, 0.f};
-      if (bv[i] && kv) {
-        if (p.wvec) {
-          v = ldg4(wp);
-        } else {
+  for (int i = 0; i < BI; ++i) pb[i] = wrow[i] + (int64_t)(ky * p.kw + kx) * p.wcs + ci;
+
+  f4 ra[AI], rb[BI];
+  auto gload = [&]() {   // loads the chunk the walk currently points at, then advances the walk by 16
+    const bool kv = k < p.K && ci < p.cval;
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (ci + e < p.Cin) v[e] = wp[e];
+    for (int i = 0; i < AI; ++i) ra[i] = ldg4_or_zero(va[i] && kv, pa[i]);
+#pragma unroll
+    for (int i = 0; i < BI; ++i) rb[i] = ldw4_or_zero(bv[i] && kv, WVEC, pb[i], ci, p.Cin);
+    k += 16;
+    ci += 16;
+    if (aligned) {   // c4 % 16 == 0: all quads of a chunk sit in one tap, so this branch is wave-uniform (and rare)
+      if (ci >= p.c4) {
+        ci -= p.c4;
+        if (++kx == p.kw) {
+          kx = 0;
+          ++ky;
         }
+        locate();
+#pragma unroll
+        for (int i = 0; i < BI; ++i) pb[i] += 16 + p.wcs - p.c4;
+      } else {
+#pragma unroll
+        for (int i = 0; i < AI; ++i) pa[i] += 16;
+#pragma unroll
+        for (int i = 0; i < BI; ++i) pb[i] += 16;
       }
-      rb[i] = v;
+    } else {         // ragged channel counts: lanes cross tap boundaries at different chunks -> re-locate every chunk, no divergence
+      int adj = 16;
+      while (ci >= p.c4) {   // one iteration unless c4 < 16
+        ci -= p.c4;
+        adj += p.wcs - p.c4;
+        const bool w = ++kx == p.kw;
+        kx = w ? 0 : kx;
+        ky += w ? 1 : 0;
+      }
+      locate();
+#pragma unroll
+      for (int i = 0; i < BI; ++i) pb[i] += adj;
     }
   };
   auto sstore = [&](int buf) {
@@ -151,16 +205,42 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(IgemmArgs p) {
     for (int j = 0; j < NT; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = (p.K + 15) >> 4;
-  gload(0);
+  gload();
   sstore(0);
   __syncthreads();
-  for (int kc = 0; kc < nk; ++kc) {
+  // steady state: one basic block per chunk (prefetch of chunk kc+1 is unconditional; the last chunk is peeled) so that the
+  // scheduler directives below can interleave the gather's address arithmetic / loads with the MFMA stream
+  const bool dbg = p.dbg != nullptr && blockIdx.x == 9 && tid == 0;
+  long long t_load = 0, t_mma = 0, t_store = 0, t_bar = 0;
+  for (int kc = 0; kc + 1 < nk; ++kc) {
     const int buf = kc & 1;
-    if (kc + 1 < nk) gload(kc + 1);
+    long long c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0;
+    if (p.dbg) { __builtin_amdgcn_sched_barrier(0); c0 = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
+    gload();
+    if (p.dbg) { __builtin_amdgcn_sched_barrier(0); c1 = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
     mma_kcontig_a_kcontig_b<MT, NT>(sA + buf * BM * 16, sB + buf * BN * 16, wm * MT * 16, wn * NT * 16, lane, acc);
-    if (kc + 1 < nk) sstore(buf ^ 1);
+    __builtin_amdgcn_sched_barrier(0);   // keep the LDS stores (which wait for the prefetch) behind the MFMA stream
+    if (p.dbg) { c2 = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
+    sstore(buf ^ 1);
+    if (p.dbg) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); c3 = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
+    if (SCHED == 1) {
+#pragma unroll
+      for (int g = 0; g < MT * NT * 4; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);  // 4 VALU
+      }
+    } else if (SCHED == 2) {
+      __builtin_amdgcn_iglp_opt(0);
+    }
     __syncthreads();
+    if (p.dbg) {
+      __builtin_amdgcn_sched_barrier(0);
+      c4 = __builtin_readcyclecounter();
+      t_load += c1 - c0; t_mma += c2 - c1; t_store += c3 - c2; t_bar += c4 - c3;
+    }
   }
+  if (dbg) { p.dbg[0] = t_load; p.dbg[1] = t_mma; p.dbg[2] = t_store; p.dbg[3] = t_bar; p.dbg[4] = nk - 1; }
+  mma_kcontig_a_kcontig_b<MT, NT>(sA + ((nk - 1) & 1) * BM * 16, sB + ((nk - 1) & 1) * BN * 16, wm * MT * 16, wn * NT * 16, lane, acc);
 
   const int lr = lane & 15, lq = lane >> 4;
 #pragma unroll
@@ -174,6 +254,113 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(IgemmArgs p) {
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
         const int m = m0 + wm * MT * 16 + i * 16 + lq * 4 + rg;
+        if (m < p.M) p.out[(int64_t)m * p.ycs + col] = cvalid ? cat::apply_act(acc[i][j][rg] + bias, p.act, p.slope) : 0.f;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ forward, direct fragments
+// GEMM-N <= 96: the whole N extent fits one wave tile, so A rows are never shared between waves and the MFMA fragment layout
+// (row = lane&15, k-quad = lane>>4) is itself a legal coalescing pattern (16 pixels x 64 B per load).  Fragments therefore go
+// global -> VGPR -> MFMA with NO LDS and NO barrier: each wave runs its own 2-deep register pipeline and the 4..8 resident
+// waves per SIMD hide the gather latency.  Workgroup = 4 independent waves; wave tile = (MT*16) x (NT*16).
+template <int MT, int NT>
+__global__ __launch_bounds__(256) void conv_fwd_direct_kernel(IgemmArgs p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lr = lane & 15, lq = lane >> 4;
+  const int ntn = (p.Cout + NT * 16 - 1) / (NT * 16);
+  const int bid = cat::xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = ((bid / ntn) * 4 + wave) * MT * 16, n0 = (bid % ntn) * NT * 16;
+  if (m0 >= p.M) return;
+  const int HoWo = p.Ho * p.Wo;
+  const int taps = p.kh * p.kw;
+
+  int iy0[MT], ix0[MT];
+  int64_t xoff[MT];
+  bool rv[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int m = m0 + i * 16 + lr;
+    rv[i] = m < p.M;
+    const int mm = rv[i] ? m : 0;
+    const int n = mm / HoWo, rem = mm - n * HoWo;
+    const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+    iy0[i] = oy * p.stride - p.pad;
+    ix0[i] = ox * p.stride - p.pad;
+    xoff[i] = (int64_t)n * p.H * p.W * p.xcs;
+  }
+  const float* wrow[NT];
+  bool bv[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int co = n0 + j * 16 + lr;
+    bv[j] = co < p.Cout;
+    wrow[j] = p.b + (int64_t)(bv[j] ? co : 0) * taps * p.wcs;
+  }
+
+  auto gload = [&](int kc, f4 (&fa)[MT], f4 (&fb)[NT]) {
+    const int k = kc * 16 + lq * 4;
+    const bool kin = k < p.K;
+    const int tap = kin ? k / p.c4 : 0, ci = kin ? k - tap * p.c4 : 0;
+    const bool kv = kin && ci < p.cval;
+    const int ky = tap / p.kw, kx = tap - ky * p.kw;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      int iy = iy0[i] + ky, ix = ix0[i] + kx;
+      bool v = rv[i] && kv;
+      {  // branch-free: reflect -> mirrored index, zero padding -> invalid lane (reads the zero page)
+        const bool inr = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        const int ry = cat::reflect_idx(iy, p.H), rx = cat::reflect_idx(ix, p.W);
+        iy = p.reflect ? ry : (inr ? iy : 0);
+        ix = p.reflect ? rx : (inr ? ix : 0);
+        v = v && (p.reflect || inr);
+      }
+      fa[i] = ldg4_or_zero(v, p.a + xoff[i] + ((int64_t)iy * p.W + ix) * p.xcs + ci);
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      fb[j] = ldw4_or_zero(bv[j] && kv, p.wvec, wrow[j] + (int64_t)tap * p.wcs + ci, ci, p.Cin);
+    }
+  };
+  auto mma = [&](const f4 (&fa)[MT], const f4 (&fb)[NT], f4 (&acc)[MT][NT]) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][t], fb[j][t], acc[i][j], 0, 0, 0);
+  };
+
+  f4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (p.K + 15) >> 4;
+  f4 a0[MT], b0[NT], a1[MT], b1[NT];
+  gload(0, a0, b0);
+  for (int kc = 0; kc < nk; kc += 2) {
+    if (kc + 1 < nk) gload(kc + 1, a1, b1);
+    mma(a0, b0, acc);
+    if (kc + 1 < nk) {
+      if (kc + 2 < nk) gload(kc + 2, a0, b0);
+      mma(a1, b1, acc);
+    }
+  }
+
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int col = n0 + j * 16 + lr;
+    const bool cvalid = col < p.Cout;
+    const float bias = (cvalid && p.bias) ? p.bias[col] : 0.f;
+    if (!cvalid && col >= p.cw) continue;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int m = m0 + i * 16 + lq * 4 + rg;
         if (m < p.M) p.out[(int64_t)m * p.ycs + col] = cvalid ? cat::apply_act(acc[i][j][rg] + bias, p.act, p.slope) : 0.f;
       }
     }
@@ -225,43 +412,107 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(IgemmArgs p) {
     aoff[i] = (int64_t)n * p.Ho * p.Wo * p.ycs;
   }
 
-  f4 ra[AI], rb[BI];
-  auto gload = [&](int kc) {
-    {
-      const int k = kc * 16 + q * 4;
-      const bool kv = k < K;
-      const int tj = kv ? k / p.c4 : 0, co = kv ? k - tj * p.c4 : 0;
-      const int jy = ntx ? tj / ntx : 0, jx = tj - jy * ntx;
+  // incremental K walk (see conv_fwd_kernel): A quad = (tap (jy,jx), co..co+3) of dy; B rows = 16 consecutive k of the chunk
+  const bool aligned = (p.c4 & 15) == 0;
+  int ka = q * 4, aco, ajy, ajx;
+  {
+    const int tj = p.c4 ? ka / p.c4 : 0;
+    aco = ka - tj * p.c4;
+    ajy = ntx ? tj / ntx : 0;
+    ajx = tj - ajy * ntx;
+  }
+  const float* pa[AI];
+  bool va[AI];
+  auto locate_a = [&]() {
 #pragma unroll
-      for (int i = 0; i < AI; ++i) {
-        const int oy = cy[i] - jy, ox = cx[i] - jx;
-        const bool v = rv[i] && kv && (unsigned)oy < (unsigned)p.Ho && (unsigned)ox < (unsigned)p.Wo;
-        ra[i] = v ? ldg4(p.a + aoff[i] + ((int64_t)oy * p.Wo + ox) * p.ycs + co) : f4{0.f, 0.f, 0.f, 0.f};
-      }
+    for (int i = 0; i < AI; ++i) {
+      const int oy = cy[i] - ajy, ox = cx[i] - ajx;
+      const bool inr = (unsigned)oy < (unsigned)p.Ho && (unsigned)ox < (unsigned)p.Wo;
+      va[i] = rv[i] && inr;
+      pa[i] = p.a + aoff[i] + ((int64_t)(inr ? oy : 0) * p.Wo + (inr ? ox : 0)) * p.ycs + aco;
     }
+  };
+  locate_a();
+  int kb[BI], bco[BI], bjy[BI], bjx[BI], bci[BI];
+  const float* pb[BI];
+  bool vb[BI];
+  auto locate_b = [&](int i) {
+    const int ky = py + bjy[i] * s, kx = px + bjx[i] * s;
+    vb[i] = bco[i] < p.Cout && bci[i] < p.Cin;
+    pb[i] = p.b + ((int64_t)(vb[i] ? bco[i] : 0) * taps + ky * p.kw + kx) * p.wcs + bci[i];
+  };
+#pragma unroll
+  for (int i = 0; i < BI; ++i) {
+    const int idx = tid + 256 * i;
+    const int kr = idx / BQ, nq = idx - kr * BQ;
+    kb[i] = kr < 16 ? kr : (1 << 30);   // rows >= 16 (thread has no work in this slot) never become valid
+    const int kk = kr < 16 ? kr : 0;
+    const int tj = p.c4 ? kk / p.c4 : 0;
+    bco[i] = kk - tj * p.c4;
+    bjy[i] = ntx ? tj / ntx : 0;
+    bjx[i] = tj - bjy[i] * ntx;
+    bci[i] = n0 + nq * 4;
+    locate_b(i);
+  }
+
+  f4 ra[AI], rb[BI];
+  auto gload = [&]() {
+    const bool kva = ka < K && aco < p.cval;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) ra[i] = ldg4_or_zero(va[i] && kva, pa[i]);
+#pragma unroll
+    for (int i = 0; i < BI; ++i) rb[i] = ldw4_or_zero(vb[i] && kb[i] < K, p.wvec, pb[i], bci[i], p.Cin);
+    ka += 16;
+    aco += 16;
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
-      const int idx = tid + 256 * i;
-      const int kr = idx / BQ, nq = idx - kr * BQ;
-      f4 v = {0.f, 0.f, 0.f, 0.f};
-      const int k = kc * 16 + kr;
-      if (kr < 16 && k < K) {
-        const int tj = k / p.c4, co = k - tj * p.c4;
-        const int jy = tj / ntx, jx = tj - jy * ntx;
-        const int ky = py + jy * s, kx = px + jx * s;
-        const int ci = n0 + nq * 4;
-        if (co < p.Cout && ci < p.Cin) {
-          const float* wp = p.b + ((int64_t)co * taps + ky * p.kw + kx) * p.Cin + ci;
-          if (p.wvec) {
-            v = ldg4(wp);
-          } else {
+      kb[i] += 16;
+      bco[i] += 16;
+    }
+    if (aligned) {   // wave-uniform: every quad / row of the chunk wraps to the next tap together
+      if (aco >= p.c4) {
+        aco -= p.c4;
+        if (++ajx == ntx) {
+          ajx = 0;
+          ++ajy;
+        }
+        locate_a();
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (ci + e < p.Cin) v[e] = wp[e];
+        for (int i = 0; i < BI; ++i) {
+          bco[i] -= p.c4;
+          if (++bjx[i] == ntx) {
+            bjx[i] = 0;
+            ++bjy[i];
           }
+          locate_b(i);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < AI; ++i) pa[i] += 16;
+#pragma unroll
+        for (int i = 0; i < BI; ++i) {
+          vb[i] = bco[i] < p.Cout && bci[i] < p.Cin;
+          pb[i] += (int64_t)16 * taps * p.wcs;
         }
       }
-      rb[i] = v;
+    } else {
+      while (aco >= p.c4) {
+        aco -= p.c4;
+        const bool w = ++ajx == ntx;
+        ajx = w ? 0 : ajx;
+        ajy += w ? 1 : 0;
+      }
+      locate_a();
+#pragma unroll
+      for (int i = 0; i < BI; ++i) {
+        while (bco[i] >= p.c4) {
+          bco[i] -= p.c4;
+          const bool w = ++bjx[i] == ntx;
+          bjx[i] = w ? 0 : bjx[i];
+          bjy[i] += w ? 1 : 0;
+        }
+        locate_b(i);
+      }
     }
   };
   auto sstore = [&](int buf) {
@@ -284,13 +535,13 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(IgemmArgs p) {
   const int lr = lane & 15, lq = lane >> 4;
   const int nk = (K + 15) >> 4;
   if (nk > 0) {
-    gload(0);
+    gload();
     sstore(0);
   }
   __syncthreads();
   for (int kc = 0; kc < nk; ++kc) {
     const int buf = kc & 1;
-    if (kc + 1 < nk) gload(kc + 1);
+    if (kc + 1 < nk) gload();
     {
       const float* A = sA + buf * BM * 16;
       const float* B = sB + buf * 16 * LDB;
@@ -393,13 +644,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(IgemmArgs p) {
     pox[i] = rem - poy[i] * p.Wo;
   }
   // NB: gload must be called with kc = 0, 1, 2, ... exactly once each, in order
+  const float* pa[AI];
+#pragma unroll
+  for (int i = 0; i < AI; ++i) pa[i] = p.b + (int64_t)(mbeg + apix[i]) * p.ycs + c0 + acq[i] * 4;
   f4 ra[AI], rb[BI];
   auto gload = [&](int kc) {
     const int mb = mbeg + kc * 16;
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
-      const int m = mb + apix[i];
-      ra[i] = (acv[i] && m < mend) ? ldg4(p.b + (int64_t)m * p.ycs + c0 + acq[i] * 4) : f4{0.f, 0.f, 0.f, 0.f};
+      ra[i] = ldg4_or_zero(acv[i] && mb + apix[i] < mend, pa[i]);
+      pa[i] += 16 * p.ycs;
     }
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
@@ -415,13 +669,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(IgemmArgs p) {
         }
       }
       int iy = oy * p.stride - p.pad + bky[i], ix = ox * p.stride - p.pad + bkx[i];
-      if (p.reflect) {
-        iy = cat::reflect_idx(iy, p.H);
-        ix = cat::reflect_idx(ix, p.W);
-      } else {
-        v = v && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      {  // branch-free: reflect -> mirrored index, zero padding -> invalid lane (reads the zero page)
+        const bool inr = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        const int ry = cat::reflect_idx(iy, p.H), rx = cat::reflect_idx(ix, p.W);
+        iy = p.reflect ? ry : (inr ? iy : 0);
+        ix = p.reflect ? rx : (inr ? ix : 0);
+        v = v && (p.reflect || inr);
       }
-      rb[i] = v ? ldg4(p.a + ((int64_t)n * p.H * p.W + (int64_t)iy * p.W + ix) * p.xcs + bci[i]) : f4{0.f, 0.f, 0.f, 0.f};
+      rb[i] = ldg4_or_zero(v, p.a + (unsigned)(((n * p.H + iy) * p.W + ix) * p.xcs + bci[i]));   // < 2^32 elements (checked on the host)
     }
   };
   auto sstore = [&](int buf) {
@@ -484,8 +739,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(IgemmArgs p) {
         const int co = c0 + wm * MT * 16 + i * 16 + lq * 4 + rg;
         if (co >= p.Cout) continue;
         if (p.direct) {
-          if (ci < p.Cin) {
-            float* dst = p.out + ((int64_t)co * taps + tap) * p.Cin + ci;
+          if (ci < p.cval) {   // cval = writable channels per tap (Cin, or the padded extent when the storage is padded)
+            float* dst = p.out + ((int64_t)co * taps + tap) * p.wcs + ci;
             *dst = p.accumulate ? *dst + acc[i][j][rg] : acc[i][j][rg];
           }
         } else {
@@ -497,17 +752,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(IgemmArgs p) {
 }
 
 // dw[co][tap][ci] (+)= sum_z ws[z][co][tap*c4 + ci]; 64 outputs x 4 split-lanes per workgroup (coalesced in ci)
+// wlim = channels written per tap (Cin for dense storage, the padded extent otherwise), wcs = storage stride per tap
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nsplit,
-                                                           int Cout, int taps, int Cin, int c4, int K, int accumulate) {
+                                                           int Cout, int taps, int wlim, int wcs, int c4, int K, int accumulate) {
   __shared__ float red[256];
-  const int64_t total = (int64_t)Cout * taps * Cin;
+  const int64_t total = (int64_t)Cout * taps * wlim;
   const int64_t e = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
   const int zl = threadIdx.x >> 6;
   float s = 0.f;
+  int64_t dst = 0;
   if (e < total) {
-    const int ci = (int)(e % Cin);
-    const int64_t ct = e / Cin;
+    const int ci = (int)(e % wlim);
+    const int64_t ct = e / wlim;
     const int tap = (int)(ct % taps), co = (int)(ct / taps);
+    dst = ((int64_t)co * taps + tap) * wcs + ci;
     const float* src = ws + (int64_t)co * K + tap * c4 + ci;
     for (int z = zl; z < nsplit; z += 4) s += src[(int64_t)z * Cout * K];
   }
@@ -516,7 +774,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   if (zl == 0 && e < total) {
     const int l = threadIdx.x;
     s = (red[l] + red[l + 64]) + (red[l + 128] + red[l + 192]);
-    dw[e] = accumulate ? dw[e] + s : s;
+    dw[dst] = accumulate ? dw[dst] + s : s;
   }
 }
 
@@ -550,9 +808,18 @@ int fill_common(IgemmArgs& a, const cat_conv_t* g) {
   a.Ho = g->Ho; a.Wo = g->Wo; a.Cout = g->Cout; a.ycs = g->ycs;
   a.kh = g->kh; a.kw = g->kw; a.stride = g->stride; a.pad = g->pad; a.reflect = g->pad_mode == CAT_PAD_REFLECT;
   a.act = g->act; a.slope = g->slope;
-  a.wvec = (g->Cin % 4) == 0;
+  a.wcs = g->wcs > 0 ? g->wcs : g->Cin;
+  CAT_REQUIRE(a.wcs >= g->Cin, "conv: wcs < Cin");
+  a.wvec = (a.wcs % 4) == 0;
   a.M = g->N * g->Ho * g->Wo;
   return 0;
+}
+
+// per-tap K extent of the fwd / dgrad walk: rounding the channel count up to 16 keeps every 16-wide chunk inside one tap (uniform,
+// division-free walk) at the price of zero-filled MFMA work -- taken when that padding is <= 12.5 %
+int walk_extent(int c4) {
+  const int c16 = (c4 + 15) & ~15;
+  return (c16 - c4) * 8 <= c16 ? c16 : c4;
 }
 
 struct WgradPlan { int nsplit, mchunk, tiles; };
@@ -582,8 +849,11 @@ int cat_conv2d_fwd(const cat_conv_t* g, const float* x, const float* w, const fl
   IgemmArgs a{};
   if (int e = fill_common(a, g)) return e;
   a.a = x; a.b = w; a.bias = bias; a.out = y;
-  a.c4 = (g->Cin + 3) & ~3;
+  a.cval = (g->Cin + 3) & ~3;
+  a.c4 = walk_extent(a.cval);
   a.K = g->kh * g->kw * a.c4;
+  static const int ablate = getenv("CAT_ABLATE") ? atoi(getenv("CAT_ABLATE")) : 0;
+  a.ablate = ablate;
   a.cw = g->ycw > g->Cout ? g->ycw : g->Cout;
   CAT_REQUIRE(a.cw <= g->ycs, "conv fwd: ycw > ycs");
   hipStream_t s = (hipStream_t)stream;
@@ -592,13 +862,49 @@ int cat_conv2d_fwd(const cat_conv_t* g, const float* x, const float* w, const fl
     return cat::smallco_fwd(g, x, w, bias, y, s);
   }
   const double prof_flops = 2.0 * (double)g->N * g->Ho * g->Wo * g->Cout * g->kh * g->kw * g->Cin;
+  static const int sched = getenv("CAT_SCHED") ? atoi(getenv("CAT_SCHED")) : 0;
+  static const int lds_pad = getenv("CAT_LDS_PAD") ? atoi(getenv("CAT_LDS_PAD")) : 0;  // diagnostics: caps workgroups/CU
+  static long long* dbg_buf = nullptr;
+  if (getenv("CAT_DBG")) {
+    if (!dbg_buf) (void)hipMalloc(&dbg_buf, 64);
+    (void)hipMemsetAsync(dbg_buf, 0, 64, s);
+    a.dbg = dbg_buf;
+  }
 #define LAUNCH(MT, NT, WM, WN)                                                             \
   {                                                                                        \
     cat::ProfScope prof("conv_fwd_" #MT "x" #NT "x" #WM "x" #WN, prof_flops, 0.0, stream); \
     const int grid = cdiv(a.M, WM * MT * 16) * cdiv(a.Cout, WN * NT * 16);                 \
-    conv_fwd_kernel<MT, NT, WM, WN><<<grid, 256, 0, s>>>(a);                                \
+    if (!a.wvec) conv_fwd_kernel<MT, NT, WM, WN, false, 0><<<grid, 256, 0, s>>>(a);         \
+    else if (WN == 2 && sched == 1) conv_fwd_kernel<MT, NT, WM, WN, true, (WN == 2 ? 1 : 0)><<<grid, 256, 0, s>>>(a); \
+    else if (WN == 2 && sched == 2) conv_fwd_kernel<MT, NT, WM, WN, true, (WN == 2 ? 2 : 0)><<<grid, 256, 0, s>>>(a); \
+    else conv_fwd_kernel<MT, NT, WM, WN, true, 0><<<grid, 256, lds_pad, s>>>(a);            \
   }
-  DISPATCH_TILE_N(a.Cout, LAUNCH);
+  static const int direct_maxn = getenv("CAT_DIRECT_MAXN") ? atoi(getenv("CAT_DIRECT_MAXN")) : 48;
+#define LAUNCH_DIRECT(MT, NT)                                                                \
+  {                                                                                          \
+    cat::ProfScope prof("conv_fwd_direct_" #MT "x" #NT, prof_flops, 0.0, stream);            \
+    const int grid = cdiv(a.M, 4 * MT * 16) * cdiv(a.Cout, NT * 16);                         \
+    conv_fwd_direct_kernel<MT, NT><<<grid, 256, 0, s>>>(a);                                   \
+  }
+  if (a.Cout <= direct_maxn) {
+    if (a.Cout <= 16) LAUNCH_DIRECT(4, 1)
+    else if (a.Cout <= 32) LAUNCH_DIRECT(4, 2)
+    else if (a.Cout <= 48) LAUNCH_DIRECT(2, 3)
+    else if (a.Cout <= 64) LAUNCH_DIRECT(2, 4)
+    else LAUNCH_DIRECT(2, 6)
+  } else {
+    DISPATCH_TILE_N(a.Cout, LAUNCH);
+  }
+  if (a.dbg) {
+    long long h[8];
+    (void)hipMemcpyAsync(h, dbg_buf, 64, hipMemcpyDeviceToHost, s);
+    (void)hipStreamSynchronize(s);
+    fprintf(stderr, "[cat dbg raw] %lld %lld %lld %lld %lld err=%s\n", h[0], h[1], h[2], h[3], h[4], hipGetErrorString(hipGetLastError()));
+    if (h[4] > 0)
+      fprintf(stderr, "[cat dbg] chunks=%lld  per chunk: gload %lld  ds_read+mfma %lld  wait+ds_write %lld  barrier %lld  (shader clocks)\n", h[4],
+              h[0] / h[4], h[1] / h[4], h[2] / h[4], h[3] / h[4]);
+  }
+#undef LAUNCH_DIRECT
 #undef LAUNCH
   return cat::check_launch("conv2d_fwd");
 }
@@ -608,7 +914,8 @@ int cat_conv2d_dgrad(const cat_conv_t* g, const float* dy, const float* w, const
   IgemmArgs a{};
   if (int e = fill_common(a, g)) return e;
   a.a = dy; a.b = w; a.bias = bias; a.out = dx;
-  a.c4 = (g->Cout + 3) & ~3;
+  a.cval = (g->Cout + 3) & ~3;
+  a.c4 = walk_extent(a.cval);
   a.cw = dxcw > g->Cin ? dxcw : g->Cin;
   a.ocs = dxcs;
   CAT_REQUIRE(dxcs >= a.cw, "conv dgrad: dxcw > dxcs");
@@ -641,8 +948,10 @@ int cat_conv2d_wgrad(const cat_conv_t* g, const float* x, const float* dy, float
   IgemmArgs a{};
   if (int e = fill_common(a, g)) return e;
   const WgradPlan pl = wgrad_plan(g);
+  CAT_REQUIRE((int64_t)g->N * g->H * g->W * g->xcs < (int64_t)4294967295LL, "conv wgrad: activation larger than 2^32 elements");
   a.a = x; a.b = dy;
   a.c4 = (g->Cin + 3) & ~3;
+  a.cval = a.wcs >= a.c4 ? a.c4 : g->Cin;   // channels written per tap
   a.K = g->kh * g->kw * a.c4;
   a.nsplit = pl.nsplit; a.mchunk = pl.mchunk;
   a.direct = pl.nsplit == 1 ? 1 : 0;
@@ -654,9 +963,9 @@ int cat_conv2d_wgrad(const cat_conv_t* g, const float* x, const float* dy, float
     const double fl = 2.0 * (double)g->N * g->Ho * g->Wo * g->Cout * g->kh * g->kw * g->Cin;
     cat::ProfScope prof("conv_wgrad_smallco", fl, 0.0, stream);
     if (int e = cat::smallco_wgrad(g, x, dy, (float*)ws, s)) return e;
-    const int64_t total = (int64_t)a.Cout * a.kh * a.kw * a.Cin;
+    const int64_t total = (int64_t)a.Cout * a.kh * a.kw * a.cval;
     wgrad_reduce_kernel<<<(int)((total + 63) / 64), 256, 0, s>>>((const float*)ws, dw, cat::smallco_wgrad_nblk(g), a.Cout, a.kh * a.kw,
-                                                                  a.Cin, a.c4, a.K, accumulate);
+                                                                  a.cval, a.wcs, a.c4, a.K, accumulate);
     return cat::check_launch("conv2d_wgrad_reduce");
   }
   CAT_REQUIRE(a.direct || ws != nullptr, "conv wgrad: workspace required");
@@ -676,9 +985,9 @@ int cat_conv2d_wgrad(const cat_conv_t* g, const float* x, const float* dy, float
 #undef LAUNCH
   if (int e = cat::check_launch("conv2d_wgrad")) return e;
   if (!a.direct) {
-    const int64_t total = (int64_t)a.Cout * a.kh * a.kw * a.Cin;
+    const int64_t total = (int64_t)a.Cout * a.kh * a.kw * a.cval;
     const int grid = (int)((total + 63) / 64);
-    wgrad_reduce_kernel<<<grid, 256, 0, s>>>((const float*)ws, dw, pl.nsplit, a.Cout, a.kh * a.kw, a.Cin, a.c4, a.K, accumulate);
+    wgrad_reduce_kernel<<<grid, 256, 0, s>>>((const float*)ws, dw, pl.nsplit, a.Cout, a.kh * a.kw, a.cval, a.wcs, a.c4, a.K, accumulate);
     return cat::check_launch("conv2d_wgrad_reduce");
   }
   return 0;

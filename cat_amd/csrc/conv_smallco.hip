@@ -15,7 +15,7 @@ struct Args {
   const float* x; const float* w; const float* bias; const float* dy; float* y; float* part;
   int N, H, W, Cin, xcs, Ho, Wo, Cout, ycs, kh, kw, pad, reflect, act;
   float slope;
-  int cw, c4, tiles_x, tiles_y, nblk;
+  int cw, c4, tiles_x, tiles_y, nblk, wcs;
 };
 
 __device__ __forceinline__ int src_index(int i, int n, int reflect) {  // -1 = zero padding
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void fwd_kernel(Args p) {
           for (int i = 0; i < 4; ++i) xv[i] = row[kx + 8 * i];
 #pragma unroll
           for (int c = 0; c < CO; ++c) {
-            const float* wp = p.w + ((int64_t)c * KW * KW + ky * KW + kx) * p.Cin + ci;  // wave-uniform -> scalar loads
+            const float* wp = p.w + ((int64_t)c * KW * KW + ky * KW + kx) * p.wcs + ci;  // wave-uniform -> scalar loads
             float w0, w1, w2, w3;
             if (WVEC) {
               const f4 wv = *reinterpret_cast<const f4*>(wp);
@@ -216,6 +216,7 @@ static cat_smallco::Args make_args(const cat_conv_t* g) {
   a.N = g->N; a.H = g->H; a.W = g->W; a.Cin = g->Cin; a.xcs = g->xcs; a.Ho = g->Ho; a.Wo = g->Wo; a.Cout = g->Cout; a.ycs = g->ycs;
   a.kh = g->kh; a.kw = g->kw; a.pad = g->pad; a.reflect = g->pad_mode == CAT_PAD_REFLECT; a.act = g->act; a.slope = g->slope;
   a.c4 = (g->Cin + 3) & ~3;
+  a.wcs = g->wcs > 0 ? g->wcs : g->Cin;
   return a;
 }
 
@@ -238,7 +239,7 @@ static void launch_fwd(cat_smallco::Args& a, const cat_conv_t* g, bool small_ima
 
 template <int CO, int KW>
 static void launch_fwd_v(cat_smallco::Args& a, const cat_conv_t* g, bool sm, hipStream_t s) {
-  if ((g->Cin & 3) == 0) launch_fwd<CO, KW, true>(a, g, sm, s);
+  if ((a.wcs & 3) == 0) launch_fwd<CO, KW, true>(a, g, sm, s);
   else launch_fwd<CO, KW, false>(a, g, sm, s);
 }
 

@@ -93,9 +93,12 @@ class ZeroPad2d(nn.ConstantPad2d):
 
 
 def _to_channels_last_(module):
+    """Re-house a conv weight as [O][kh][kw][round_up(I,4)] (zero padded channels_last); logical values are unchanged."""
     w = module.weight
-    if w.dim() == 4 and w.shape[1] > 1 and not w.permute(0, 2, 3, 1).is_contiguous():
-        w.data = w.data.contiguous(memory_format=torch.channels_last)
+    if w.dim() == 4 and w.shape[1] > 1 and ops.weight_wcs(w) != ops.cs_for(w.shape[1]) and w.is_cuda:
+        new = ops.padded_weight_like(w.shape, w.device)
+        new.copy_(w.data)
+        w.data = new
 
 
 class Conv2d(nn.Conv2d):

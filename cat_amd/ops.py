@@ -112,15 +112,37 @@ def conform(t):
     return y
 
 
+def padded_weight_like(shape, device):
+    """Storage for a conv weight of logical shape [O, I, kh, kw]: physical [O][kh][kw][round_up(I, 4)], zero padded."""
+    o, i, kh, kw = shape
+    buf = torch.zeros((o, kh, kw, cs_for(i)), device=device, dtype=torch.float32)
+    return buf[..., :i].permute(0, 3, 1, 2)
+
+
+def weight_wcs(w):
+    """Floats per (cout, tap) if `w` ([O, I, kh, kw]) is laid out [O][kh][kw][wcs] (dense channels_last or padded), else None."""
+    if w.dim() != 4 or w.dtype != torch.float32 or w.data_ptr() % 16:
+        return None
+    o, i, kh, kw = w.shape
+    s0, s1, s2, s3 = w.stride()
+    wcs = s3 if kw > 1 else (s2 if kh > 1 else (s0 if o > 1 else cs_for(i)))
+    ok = wcs >= i and (i == 1 or s1 == 1) and (kw == 1 or s3 == wcs) and (kh == 1 or s2 == kw * wcs) and (o == 1 or s0 == kh * kw * wcs)
+    return wcs if ok else None
+
+
 def weight_cl(w):
-    """Conv weights must be physically [O][kh][kw][I] (torch channels_last)."""
-    if w.dim() == 4 and w.permute(0, 2, 3, 1).is_contiguous():
-        return w
-    return w.contiguous(memory_format=torch.channels_last)
+    """(tensor, wcs): the weight in kernel layout.  Parameters owned by cat_amd modules / FusedAdam already are (padded
+    channels_last); anything else (a test tensor, a freshly loaded NCHW checkpoint tensor) is re-laid-out once."""
+    wcs = weight_wcs(w)
+    if wcs is not None:
+        return w, wcs
+    out = padded_weight_like(w.shape, w.device)
+    out.copy_(w.detach())
+    return out, weight_wcs(out)
 
 
-def _conv_geom(n, h, w, cin, xcs, ho, wo, cout, ycs, kh, kw, stride, pad, pad_mode, act=0, slope=0.0, ycw=0):
-    return ConvGeom(n, h, w, cin, xcs, ho, wo, cout, ycs, kh, kw, stride, pad, pad_mode, act, slope, ycw)
+def _conv_geom(n, h, w, cin, xcs, ho, wo, cout, ycs, kh, kw, stride, pad, pad_mode, act=0, slope=0.0, ycw=0, wcs=0):
+    return ConvGeom(n, h, w, cin, xcs, ho, wo, cout, ycs, kh, kw, stride, pad, pad_mode, act, slope, ycw, wcs)
 
 
 def _grad_target(param):
@@ -138,7 +160,7 @@ def _write_param_grad(param, kernel):
         st['fresh'] = False
         return None
     if param.dim() == 4 and param.shape[1] > 1:
-        g = torch.empty(param.shape, device=param.device, dtype=param.dtype, memory_format=torch.channels_last)
+        g = padded_weight_like(param.shape, param.device)
     else:
         g = torch.empty(param.shape, device=param.device, dtype=param.dtype)
     kernel(g, 0)
@@ -165,7 +187,7 @@ class Conv2dFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias, stride, pad, pad_mode, act, slope):
         _require_cuda(x)
         x = conform(x)
-        wcl = weight_cl(weight)
+        wcl, wcs = weight_cl(weight)
         n, cin, h, w = x.shape
         cout, cin_w, kh, kw = weight.shape
         if cin_w != cin:
@@ -173,9 +195,9 @@ class Conv2dFn(torch.autograd.Function):
         ho = (h + 2 * pad - kh) // stride + 1
         wo = (w + 2 * pad - kw) // stride + 1
         y = empty_act(n, cout, ho, wo, x.device)
-        g = _conv_geom(n, h, w, cin, act_cs(x), ho, wo, cout, act_cs(y), kh, kw, stride, pad, pad_mode, act, slope, act_cs(y))
+        g = _conv_geom(n, h, w, cin, act_cs(x), ho, wo, cout, act_cs(y), kh, kw, stride, pad, pad_mode, act, slope, act_cs(y), wcs)
         L.call('cat_conv2d_fwd', C.byref(g), _p(x), _p(wcl), _p(bias), _p(y), _stream())
-        ctx.geom = (n, h, w, cin, act_cs(x), ho, wo, cout, act_cs(y), kh, kw, stride, pad, pad_mode)
+        ctx.geom = (n, h, w, cin, act_cs(x), ho, wo, cout, act_cs(y), kh, kw, stride, pad, pad_mode, wcs)
         ctx.act, ctx.slope = act, slope
         ctx.weight, ctx.bias = weight, bias
         ctx.save_for_backward(x, wcl, y if act != L.ACT_NONE else None)
@@ -184,11 +206,11 @@ class Conv2dFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, wcl, y = ctx.saved_tensors
-        n, h, w, cin, xcs, ho, wo, cout, ycs, kh, kw, stride, pad, pad_mode = ctx.geom
+        n, h, w, cin, xcs, ho, wo, cout, ycs, kh, kw, stride, pad, pad_mode, wcs = ctx.geom
         dy = conform(dy)
         if ctx.act != L.ACT_NONE:
             dy = _act_bwd(y, dy, ctx.act, ctx.slope)
-        g = _conv_geom(n, h, w, cin, xcs, ho, wo, cout, act_cs(dy), kh, kw, stride, pad, pad_mode)
+        g = _conv_geom(n, h, w, cin, xcs, ho, wo, cout, act_cs(dy), kh, kw, stride, pad, pad_mode, wcs=wcs)
         st = _stream()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
@@ -204,8 +226,9 @@ class Conv2dFn(torch.autograd.Function):
             ws = workspace(L.query('cat_conv2d_wgrad_ws_bytes', C.byref(g)), x.device)
 
             def k(dst, acc):
-                L.call('cat_conv2d_wgrad', C.byref(g), _p(x), _p(dy), _p(dst), acc, _p(ws), st)
-            dw = _write_param_grad(ctx.weight, lambda dst, acc: k(_as_cl(dst), acc))
+                gw = _conv_geom(n, h, w, cin, xcs, ho, wo, cout, act_cs(dy), kh, kw, stride, pad, pad_mode, wcs=_grad_wcs(dst))
+                L.call('cat_conv2d_wgrad', C.byref(gw), _p(x), _p(dy), _p(dst), acc, _p(ws), st)
+            dw = _write_param_grad(ctx.weight, k)
         if ctx.bias is not None and ctx.needs_input_grad[2]:
             m = n * ho * wo
             ws = workspace(L.query('cat_channel_sum_ws_bytes', m, act_cs(dy)), x.device)
@@ -214,10 +237,11 @@ class Conv2dFn(torch.autograd.Function):
         return dx, dw, db, None, None, None, None, None
 
 
-def _as_cl(t):
-    if t.dim() == 4 and not t.permute(0, 2, 3, 1).is_contiguous():
-        raise RuntimeError('conv weight gradient buffer must be channels_last (physical [O][kh][kw][I])')
-    return t
+def _grad_wcs(t):
+    wcs = weight_wcs(t)
+    if wcs is None:
+        raise RuntimeError('conv weight gradient buffer must be laid out [O][kh][kw][wcs] (channels_last, optionally padded)')
+    return wcs
 
 
 class ConvTranspose2dFn(torch.autograd.Function):
@@ -228,7 +252,7 @@ class ConvTranspose2dFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias, stride, pad, output_padding):
         _require_cuda(x)
         x = conform(x)
-        wcl = weight_cl(weight)
+        wcl, wcs = weight_cl(weight)
         n, cin_t, hi, wi = x.shape
         cin_w, cout_t, kh, kw = weight.shape
         if cin_w != cin_t:
@@ -237,9 +261,9 @@ class ConvTranspose2dFn(torch.autograd.Function):
         wo = (wi - 1) * stride - 2 * pad + kw + output_padding
         y = empty_act(n, cout_t, ho, wo, x.device)
         # equivalent conv: input (ho, wo, cout_t) -> output (hi, wi, cin_t)
-        g = _conv_geom(n, ho, wo, cout_t, act_cs(y), hi, wi, cin_t, act_cs(x), kh, kw, stride, pad, L.PAD_ZERO)
+        g = _conv_geom(n, ho, wo, cout_t, act_cs(y), hi, wi, cin_t, act_cs(x), kh, kw, stride, pad, L.PAD_ZERO, wcs=wcs)
         L.call('cat_conv2d_dgrad', C.byref(g), _p(x), _p(wcl), _p(bias), _p(y), act_cs(y), act_cs(y), _stream())
-        ctx.geom = (n, ho, wo, cout_t, act_cs(y), hi, wi, cin_t, act_cs(x), kh, kw, stride, pad)
+        ctx.geom = (n, ho, wo, cout_t, act_cs(y), hi, wi, cin_t, act_cs(x), kh, kw, stride, pad, wcs)
         ctx.weight, ctx.bias = weight, bias
         ctx.save_for_backward(x, wcl)
         return y
@@ -247,19 +271,22 @@ class ConvTranspose2dFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, wcl = ctx.saved_tensors
-        n, ho, wo, cout_t, ycs, hi, wi, cin_t, xcs, kh, kw, stride, pad = ctx.geom
+        n, ho, wo, cout_t, ycs, hi, wi, cin_t, xcs, kh, kw, stride, pad, wcs = ctx.geom
         dy = conform(dy)
         st = _stream()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = empty_act(n, cin_t, hi, wi, x.device)
-            g = _conv_geom(n, ho, wo, cout_t, act_cs(dy), hi, wi, cin_t, act_cs(dx), kh, kw, stride, pad, L.PAD_ZERO, 0, 0.0, act_cs(dx))
+            g = _conv_geom(n, ho, wo, cout_t, act_cs(dy), hi, wi, cin_t, act_cs(dx), kh, kw, stride, pad, L.PAD_ZERO, 0, 0.0, act_cs(dx), wcs)
             L.call('cat_conv2d_fwd', C.byref(g), _p(dy), _p(wcl), None, _p(dx), st)
         if ctx.needs_input_grad[1]:
             g = _conv_geom(n, ho, wo, cout_t, act_cs(dy), hi, wi, cin_t, xcs, kh, kw, stride, pad, L.PAD_ZERO)
             ws = workspace(L.query('cat_conv2d_wgrad_ws_bytes', C.byref(g)), x.device)
-            dw = _write_param_grad(ctx.weight, lambda dst, acc: L.call('cat_conv2d_wgrad', C.byref(g), _p(dy), _p(x), _p(_as_cl(dst)), acc,
-                                                                       _p(ws), st))
+
+            def k(dst, acc):
+                gw = _conv_geom(n, ho, wo, cout_t, act_cs(dy), hi, wi, cin_t, xcs, kh, kw, stride, pad, L.PAD_ZERO, wcs=_grad_wcs(dst))
+                L.call('cat_conv2d_wgrad', C.byref(gw), _p(dy), _p(x), _p(dst), acc, _p(ws), st)
+            dw = _write_param_grad(ctx.weight, k)
         if ctx.bias is not None and ctx.needs_input_grad[2]:
             m = n * ho * wo
             ws = workspace(L.query('cat_channel_sum_ws_bytes', m, act_cs(dy)), x.device)

@@ -39,23 +39,31 @@ class FusedAdam(torch.optim.Optimizer):
             dev = params[0].device
             if dev.type != 'cuda':
                 raise RuntimeError('FusedAdam runs on the GPU only (parameters are on %s)' % dev)
+            from . import ops
+            spans = []
             for p in params:
                 if p.dtype != torch.float32 or p.device != dev:
                     raise RuntimeError('FusedAdam: parameters of a group must be fp32 on one device')
-                if p.dim() == 4 and p.shape[1] > 1 and not p.permute(0, 2, 3, 1).is_contiguous():
-                    p.data = p.data.contiguous(memory_format=torch.channels_last)
-                elif not (p.is_contiguous() or (p.dim() == 4 and p.permute(0, 2, 3, 1).is_contiguous())):
-                    p.data = p.data.contiguous()
+                if p.dim() == 4 and p.shape[1] > 1:
+                    # conv weights live as [O][kh][kw][round_up(I,4)] (zero padded): every filter quad is an aligned float4
+                    if ops.weight_wcs(p) != ops.cs_for(p.shape[1]):
+                        new = ops.padded_weight_like(p.shape, dev)
+                        new.copy_(p.data)
+                        p.data = new
+                    spans.append(p.shape[0] * p.shape[2] * p.shape[3] * ops.cs_for(p.shape[1]))
+                else:
+                    if not p.is_contiguous():
+                        p.data = p.data.contiguous()
+                    spans.append(p.numel())
             # 16-byte align every segment so float4 kernels can address parameters directly
             offs, total = [], 0
-            for p in params:
+            for span in spans:
                 offs.append(total)
-                total += (p.numel() + 3) // 4 * 4
+                total += (span + 3) // 4 * 4
             fp = torch.zeros(total, device=dev, dtype=torch.float32)
             fg = torch.zeros(total, device=dev, dtype=torch.float32)
-            for p, off in zip(params, offs):
-                n = p.numel()
-                fp[off:off + n].copy_(self._dense_1d(p.data))
+            for p, off, span in zip(params, offs, spans):
+                fp[off:off + span].copy_(torch.as_strided(p.data, (span,), (1,), p.storage_offset()))
                 shape, stride = tuple(p.shape), tuple(p.stride())
                 p.data = torch.as_strided(fp, shape, stride, off)
                 gv = torch.as_strided(fg, shape, stride, off)

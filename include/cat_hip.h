@@ -9,8 +9,9 @@
  *   - All tensors are fp32, resident in HBM, NHWC ("channels last").  An activation is described by
  *     (ptr, N, H, W, C, cs): cs = floats per pixel (>= C, multiple of 4); channels [C, cs) are padding that
  *     kernels keep at 0.0f.  ptr is 16-byte aligned.
- *   - Conv weights are [Cout][kh][kw][Cin] (= torch OIHW in channels_last memory format, unpadded);
- *     ConvTranspose2d weights are [Cin_t][kh][kw][Cout_t] (= torch IOHW channels_last).
+ *   - Conv weights are [Cout][kh][kw][wcs] with wcs >= Cin (= torch OIHW in channels_last memory format; cat_amd stores
+ *     them with wcs = round_up(Cin, 4) and zero padding so that every filter quad is one aligned float4 load);
+ *     ConvTranspose2d weights are [Cin_t][kh][kw][wcs >= Cout_t] (= torch IOHW channels_last).
  *   - Every function enqueues on `stream` and returns immediately: 0 on success, negative on a bad
  *     argument / launch failure (text via cat_hip_last_error()).  Nothing is allocated; scratch is passed in.
  */
@@ -41,6 +42,7 @@ typedef struct {
   int act;                 /* fused epilogue activation (fwd only) */
   float slope;             /* LeakyReLU slope */
   int ycw;                 /* fwd: channels [Cout, ycw) of y are written as 0 (ycw<=ycs); 0 -> Cout */
+  int wcs;                 /* weight floats per (cout, tap): w is [Cout][kh][kw][wcs], channels [Cin, wcs) zero; 0 -> Cin (dense) */
 } cat_conv_t;
 
 /* y = act(conv(x, w) + bias); bias may be NULL. */

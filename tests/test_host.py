@@ -29,12 +29,17 @@ def test_state_dict_keys_match_reference(tag, norm, track):
 
 
 def test_weights_are_channels_last_after_flatten_rules():
-    from cat_amd import nn as cnn
-    c = cnn.Conv2d(8, 4, 3)
-    cnn._to_channels_last_(c)
-    assert c.weight.permute(0, 2, 3, 1).is_contiguous()
+    from cat_amd import nn as cnn, ops
+    c = cnn.Conv2d(6, 4, 3)
+    ref = c.weight.detach().clone()
+    new = ops.padded_weight_like(c.weight.shape, c.weight.device)      # [O][kh][kw][round_up(I,4)], zero padded
+    new.copy_(c.weight.data)
+    c.weight.data = new
+    assert ops.weight_wcs(c.weight) == 8 and c.weight.stride() == (72, 1, 24, 8)
     sd = c.state_dict()
-    assert sd['weight'].shape == (4, 8, 3, 3)          # logical OIHW is the checkpoint format
+    assert sd['weight'].shape == (4, 6, 3, 3) and torch.equal(sd['weight'], ref)   # logical OIHW is the checkpoint format
+    assert ops.weight_wcs(ref.contiguous(memory_format=torch.channels_last)) == 6    # dense channels_last is accepted too
+    assert ops.weight_wcs(ref) is None                                               # plain NCHW-contiguous is not
 
 
 def test_factory_and_flags():
