@@ -260,28 +260,36 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(IgemmArgs p) {
   }
 }
 
-// ------------------------------------------------------------------------------------------------ forward, direct fragments
-// GEMM-N <= 96: the whole N extent fits one wave tile, so A rows are never shared between waves and the MFMA fragment layout
-// (row = lane&15, k-quad = lane>>4) is itself a legal coalescing pattern (16 pixels x 64 B per load).  Fragments therefore go
-// global -> VGPR -> MFMA with NO LDS and NO barrier: each wave runs its own 2-deep register pipeline and the 4..8 resident
-// waves per SIMD hide the gather latency.  Workgroup = 4 independent waves; wave tile = (MT*16) x (NT*16).
-template <int MT, int NT>
-__global__ __launch_bounds__(256) void conv_fwd_direct_kernel(IgemmArgs p) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int lr = lane & 15, lq = lane >> 4;
-  const int ntn = (p.Cout + NT * 16 - 1) / (NT * 16);
+// ------------------------------------------------------------------------------------------------ forward, BK = 32
+// Same tiling as conv_fwd_kernel with 32-deep K chunks: the per-chunk fixed cost (pointer bumps, LDS stores, barrier, fragment
+// read latency: ~700 shader clocks measured) is amortised over twice the MFMA work.  Used when the per-tap K extent is a
+// multiple of 32 (so a chunk never straddles taps and the walk is wave-uniform) and the filter rows are float4-readable.
+// Invalid rows / padding taps keep their pointer parked on the zero page (increment 0), so the steady state is one 64-bit add per
+// load and nothing else on the vector ALU.
+__device__ __forceinline__ int swz32(int r, int q) { return (r * 8 + (q ^ ((r >> 1) & 7))) * 4; }
+
+template <int MT, int NT, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_fwd32_kernel(IgemmArgs p) {
+  constexpr int BM = WM * MT * 16, BN = WN * NT * 16;
+  constexpr int AI = BM / 32, BI = (BN + 31) / 32;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sA = smem;
+  float* sB = smem + 2 * BM * 32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int ntn = (p.Cout + BN - 1) / BN;
   const int bid = cat::xcd_remap(blockIdx.x, gridDim.x);
-  const int m0 = ((bid / ntn) * 4 + wave) * MT * 16, n0 = (bid % ntn) * NT * 16;
-  if (m0 >= p.M) return;
+  const int m0 = (bid / ntn) * BM, n0 = (bid % ntn) * BN;
+  const int q = tid & 7, r0 = tid >> 3;
   const int HoWo = p.Ho * p.Wo;
   const int taps = p.kh * p.kw;
 
-  int iy0[MT], ix0[MT];
-  int64_t xoff[MT];
-  bool rv[MT];
+  int iy0[AI], ix0[AI];
+  int64_t xoff[AI];
+  bool rv[AI];
 #pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    const int m = m0 + i * 16 + lr;
+  for (int i = 0; i < AI; ++i) {
+    const int m = m0 + r0 + 32 * i;
     rv[i] = m < p.M;
     const int mm = rv[i] ? m : 0;
     const int n = mm / HoWo, rem = mm - n * HoWo;
@@ -290,69 +298,123 @@ __global__ __launch_bounds__(256) void conv_fwd_direct_kernel(IgemmArgs p) {
     ix0[i] = ox * p.stride - p.pad;
     xoff[i] = (int64_t)n * p.H * p.W * p.xcs;
   }
-  const float* wrow[NT];
-  bool bv[NT];
+  // walk state (wave-uniform except for the quad offset): ci = channel of this quad inside the tap, (ky, kx) = tap
+  int ci = q * 4, ky = 0, kx = 0;
+  const float* pa[AI];
+  int inca[AI];
+  auto locate = [&]() {
+    const bool cv = ci < p.cval;
 #pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int co = n0 + j * 16 + lr;
-    bv[j] = co < p.Cout;
-    wrow[j] = p.b + (int64_t)(bv[j] ? co : 0) * taps * p.wcs;
-  }
-
-  auto gload = [&](int kc, f4 (&fa)[MT], f4 (&fb)[NT]) {
-    const int k = kc * 16 + lq * 4;
-    const bool kin = k < p.K;
-    const int tap = kin ? k / p.c4 : 0, ci = kin ? k - tap * p.c4 : 0;
-    const bool kv = kin && ci < p.cval;
-    const int ky = tap / p.kw, kx = tap - ky * p.kw;
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
+    for (int i = 0; i < AI; ++i) {
       int iy = iy0[i] + ky, ix = ix0[i] + kx;
-      bool v = rv[i] && kv;
-      {  // branch-free: reflect -> mirrored index, zero padding -> invalid lane (reads the zero page)
-        const bool inr = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-        const int ry = cat::reflect_idx(iy, p.H), rx = cat::reflect_idx(ix, p.W);
-        iy = p.reflect ? ry : (inr ? iy : 0);
-        ix = p.reflect ? rx : (inr ? ix : 0);
-        v = v && (p.reflect || inr);
-      }
-      fa[i] = ldg4_or_zero(v, p.a + xoff[i] + ((int64_t)iy * p.W + ix) * p.xcs + ci);
-    }
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      fb[j] = ldw4_or_zero(bv[j] && kv, p.wvec, wrow[j] + (int64_t)tap * p.wcs + ci, ci, p.Cin);
+      const bool inr = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      const int ry = cat::reflect_idx(iy, p.H), rx = cat::reflect_idx(ix, p.W);
+      iy = p.reflect ? ry : (inr ? iy : 0);
+      ix = p.reflect ? rx : (inr ? ix : 0);
+      const bool v = rv[i] && (p.reflect || inr) && cv;
+      pa[i] = v ? p.a + xoff[i] + ((int64_t)iy * p.W + ix) * p.xcs + ci : g_zero_page;
+      inca[i] = v ? 32 : 0;
     }
   };
-  auto mma = [&](const f4 (&fa)[MT], const f4 (&fb)[NT], f4 (&acc)[MT][NT]) {
+  locate();
+  const float* brow[BI];
+  const float* pb[BI];
+  int incb[BI];
+  bool bok[BI];
+  int tap = 0;
+  auto locate_b = [&]() {
+    const bool cv = ci < p.cval;
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][t], fb[j][t], acc[i][j], 0, 0, 0);
+    for (int i = 0; i < BI; ++i) {
+      const bool v = bok[i] && cv;
+      pb[i] = v ? brow[i] + (int64_t)tap * p.wcs + ci : g_zero_page;
+      incb[i] = v ? 32 : 0;
+    }
   };
+#pragma unroll
+  for (int i = 0; i < BI; ++i) {
+    const int r = r0 + 32 * i, co = n0 + r;
+    bok[i] = r < BN && co < p.Cout;
+    brow[i] = p.b + (int64_t)(bok[i] ? co : 0) * taps * p.wcs;
+  }
+  locate_b();
+  const bool padded = p.c4 != p.cval;   // tap extent rounded up to 32: validity of a quad changes inside a tap
 
+  f4 ra[AI], rb[BI];
+  auto gload = [&]() {
+#pragma unroll
+    for (int i = 0; i < AI; ++i) ra[i] = ldg4(pa[i]);
+#pragma unroll
+    for (int i = 0; i < BI; ++i) rb[i] = ldg4(pb[i]);
+    ci += 32;
+    const bool wrap = ci >= p.c4;   // wave-uniform (c4 is a multiple of 32)
+    if (wrap) {
+      ci -= p.c4;
+      ++tap;
+      if (++kx == p.kw) {
+        kx = 0;
+        ++ky;
+      }
+    }
+    if (wrap || padded) {
+      locate();
+      locate_b();
+    } else {
+#pragma unroll
+      for (int i = 0; i < AI; ++i) pa[i] += inca[i];
+#pragma unroll
+      for (int i = 0; i < BI; ++i) pb[i] += incb[i];
+    }
+  };
+  auto sstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < AI; ++i) *reinterpret_cast<f4*>(sA + buf * BM * 32 + swz32(r0 + 32 * i, q)) = ra[i];
+#pragma unroll
+    for (int i = 0; i < BI; ++i)
+      if (r0 + 32 * i < BN) *reinterpret_cast<f4*>(sB + buf * BN * 32 + swz32(r0 + 32 * i, q)) = rb[i];
+  };
+  const int lr = lane & 15, lq = lane >> 4;
   f4 acc[MT][NT];
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
-
-  const int nk = (p.K + 15) >> 4;
-  f4 a0[MT], b0[NT], a1[MT], b1[NT];
-  gload(0, a0, b0);
-  for (int kc = 0; kc < nk; kc += 2) {
-    if (kc + 1 < nk) gload(kc + 1, a1, b1);
-    mma(a0, b0, acc);
-    if (kc + 1 < nk) {
-      if (kc + 2 < nk) gload(kc + 2, a0, b0);
-      mma(a1, b1, acc);
+  auto mma = [&](int buf) {
+    const float* A = sA + buf * BM * 32;
+    const float* B = sB + buf * BN * 32;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      f4 fa[MT], fb[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const f4*>(A + swz32(wm * MT * 16 + i * 16 + lr, lq + 4 * h));
+#pragma unroll
+      for (int j = 0; j < NT; ++j) fb[j] = *reinterpret_cast<const f4*>(B + swz32(wn * NT * 16 + j * 16 + lr, lq + 4 * h));
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][t], fb[j][t], acc[i][j], 0, 0, 0);
     }
+  };
+
+  const int nk = p.K >> 5;   // K is a multiple of 32 on this path
+  gload();
+  sstore(0);
+  __syncthreads();
+  for (int kc = 0; kc + 1 < nk; ++kc) {
+    const int buf = kc & 1;
+    gload();
+    mma(buf);
+    __builtin_amdgcn_sched_barrier(0);
+    sstore(buf ^ 1);
+    __syncthreads();
   }
+  mma((nk - 1) & 1);
 
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
-    const int col = n0 + j * 16 + lr;
+    const int col = n0 + wn * NT * 16 + j * 16 + lr;
     const bool cvalid = col < p.Cout;
     const float bias = (cvalid && p.bias) ? p.bias[col] : 0.f;
     if (!cvalid && col >= p.cw) continue;
@@ -360,7 +422,7 @@ __global__ __launch_bounds__(256) void conv_fwd_direct_kernel(IgemmArgs p) {
     for (int i = 0; i < MT; ++i) {
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
-        const int m = m0 + i * 16 + lq * 4 + rg;
+        const int m = m0 + wm * MT * 16 + i * 16 + lq * 4 + rg;
         if (m < p.M) p.out[(int64_t)m * p.ycs + col] = cvalid ? cat::apply_act(acc[i][j][rg] + bias, p.act, p.slope) : 0.f;
       }
     }
@@ -879,22 +941,30 @@ int cat_conv2d_fwd(const cat_conv_t* g, const float* x, const float* w, const fl
     else if (WN == 2 && sched == 2) conv_fwd_kernel<MT, NT, WM, WN, true, (WN == 2 ? 2 : 0)><<<grid, 256, 0, s>>>(a); \
     else conv_fwd_kernel<MT, NT, WM, WN, true, 0><<<grid, 256, lds_pad, s>>>(a);            \
   }
-  static const int direct_maxn = getenv("CAT_DIRECT_MAXN") ? atoi(getenv("CAT_DIRECT_MAXN")) : 48;
-#define LAUNCH_DIRECT(MT, NT)                                                                \
-  {                                                                                          \
-    cat::ProfScope prof("conv_fwd_direct_" #MT "x" #NT, prof_flops, 0.0, stream);            \
-    const int grid = cdiv(a.M, 4 * MT * 16) * cdiv(a.Cout, NT * 16);                         \
-    conv_fwd_direct_kernel<MT, NT><<<grid, 256, 0, s>>>(a);                                   \
+  // BK = 32 path: per-tap K extent a multiple of 32 (allowing <= 12.5 % zero padding) and float4-readable filter rows
+  static const int no_bk32 = getenv("CAT_NO_BK32") ? atoi(getenv("CAT_NO_BK32")) : 0;
+  const int c32 = (a.cval + 31) & ~31;
+  const bool bk32 = !no_bk32 && a.wvec && (c32 - a.cval) * 8 <= c32 && !a.dbg;
+#define LAUNCH32(MT, NT, WM, WN)                                                                      \
+  {                                                                                                   \
+    cat::ProfScope prof("conv_fwd32_" #MT "x" #NT "x" #WM "x" #WN, prof_flops, 0.0, stream);          \
+    const int grid = cdiv(a.M, WM * MT * 16) * cdiv(a.Cout, WN * NT * 16);                            \
+    const size_t lds = (size_t)2 * (WM * MT * 16 + WN * NT * 16) * 32 * sizeof(float);                \
+    static bool attr_set = false;                                                                     \
+    if (!attr_set) {                                                                                  \
+      (void)hipFuncSetAttribute((const void*)conv_fwd32_kernel<MT, NT, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      attr_set = true;                                                                                \
+    }                                                                                                 \
+    conv_fwd32_kernel<MT, NT, WM, WN><<<grid, 256, lds, s>>>(a);                                       \
   }
-  if (a.Cout <= direct_maxn) {
-    if (a.Cout <= 16) LAUNCH_DIRECT(4, 1)
-    else if (a.Cout <= 32) LAUNCH_DIRECT(4, 2)
-    else if (a.Cout <= 48) LAUNCH_DIRECT(2, 3)
-    else if (a.Cout <= 64) LAUNCH_DIRECT(2, 4)
-    else LAUNCH_DIRECT(2, 6)
+  if (bk32) {
+    a.c4 = c32;
+    a.K = g->kh * g->kw * c32;
+    DISPATCH_TILE_N(a.Cout, LAUNCH32);
   } else {
     DISPATCH_TILE_N(a.Cout, LAUNCH);
   }
+#undef LAUNCH32
   if (a.dbg) {
     long long h[8];
     (void)hipMemcpyAsync(h, dbg_buf, 64, hipMemcpyDeviceToHost, s);
@@ -904,7 +974,6 @@ int cat_conv2d_fwd(const cat_conv_t* g, const float* x, const float* w, const fl
       fprintf(stderr, "[cat dbg] chunks=%lld  per chunk: gload %lld  ds_read+mfma %lld  wait+ds_write %lld  barrier %lld  (shader clocks)\n", h[4],
               h[0] / h[4], h[1] / h[4], h[2] / h[4], h[3] / h[4]);
   }
-#undef LAUNCH_DIRECT
 #undef LAUNCH
   return cat::check_launch("conv2d_fwd");
 }

@@ -60,13 +60,15 @@ def main():
                 continue
             ho, wo = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
             x = ops.to_nhwc(torch.randn(n, cin, h, w, device=dev))
-            wt = torch.randn(cout, cin, k, k, device=dev).contiguous(memory_format=torch.channels_last) if cin > 1 else torch.randn(cout, cin, k, k, device=dev)
+            wt = ops.padded_weight_like((cout, cin, k, k), dev)      # the product's weight layout: [O][kh][kw][round_up(I,4)]
+            wt.copy_(torch.randn(cout, cin, k, k, device=dev))
+            wcs = ops.weight_wcs(wt)
             y = ops.empty_act(n, cout, ho, wo, dev)
             dy = ops.to_nhwc(torch.randn(n, cout, ho, wo, device=dev))
             hp, wp = (h + 2 * p, w + 2 * p) if refl else (h, w)
             dx = ops.empty_act(n, cin, hp, wp, dev)
-            dw = torch.empty_like(wt)
-            g = L.ConvGeom(n, h, w, cin, ops.act_cs(x), ho, wo, cout, ops.act_cs(y), k, k, s, p, 1 if refl else 0, 0, 0.0, ops.act_cs(y))
+            dw = ops.padded_weight_like((cout, cin, k, k), dev)
+            g = L.ConvGeom(n, h, w, cin, ops.act_cs(x), ho, wo, cout, ops.act_cs(y), k, k, s, p, 1 if refl else 0, 0, 0.0, ops.act_cs(y), wcs)
             ws = torch.empty(max(L.query('cat_conv2d_wgrad_ws_bytes', C.byref(g)) // 4, 1), device=dev)
             flops = 2.0 * n * ho * wo * cout * k * k * cin
             P = lambda t: C.c_void_p(t.data_ptr())
