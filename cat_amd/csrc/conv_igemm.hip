@@ -280,7 +280,10 @@ __global__ __launch_bounds__(256) void conv_fwd32_kernel(IgemmArgs p) {
   const int ntn = (p.Cout + BN - 1) / BN;
   const int bid = cat::xcd_remap(blockIdx.x, gridDim.x);
   const int m0 = (bid / ntn) * BM, n0 = (bid % ntn) * BN;
-  const int q = tid & 7, r0 = tid >> 3;
+  // staging map: waves 0-1 fetch the first 16 k of the chunk, waves 2-3 the second 16, so the (tap, channel) walk is uniform
+  // inside every wave for ANY tap extent that is a multiple of 16 (a 32-chunk may straddle two taps, a 16-half never does)
+  const int half = __builtin_amdgcn_readfirstlane(wave >> 1);
+  const int q4 = tid & 3, q = half * 4 + q4, r0 = (tid & 127) >> 2;
   const int HoWo = p.Ho * p.Wo;
   const int taps = p.kh * p.kw;
 
@@ -298,12 +301,19 @@ __global__ __launch_bounds__(256) void conv_fwd32_kernel(IgemmArgs p) {
     ix0[i] = ox * p.stride - p.pad;
     xoff[i] = (int64_t)n * p.H * p.W * p.xcs;
   }
-  // walk state (wave-uniform except for the quad offset): ci = channel of this quad inside the tap, (ky, kx) = tap
-  int ci = q * 4, ky = 0, kx = 0;
+  // walk state: tap = (ky, kx), ci = channel of this quad inside the tap; advanced by 32 per chunk
+  int tap, ci, ky, kx;
+  {
+    const int k = q * 4;
+    tap = k / p.c4;
+    ci = k - tap * p.c4;
+    ky = tap / p.kw;
+    kx = tap - ky * p.kw;
+  }
   const float* pa[AI];
   int inca[AI];
   auto locate = [&]() {
-    const bool cv = ci < p.cval;
+    const bool cv = ci < p.cval && tap < taps;
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
       int iy = iy0[i] + ky, ix = ix0[i] + kx;
@@ -321,9 +331,8 @@ __global__ __launch_bounds__(256) void conv_fwd32_kernel(IgemmArgs p) {
   const float* pb[BI];
   int incb[BI];
   bool bok[BI];
-  int tap = 0;
   auto locate_b = [&]() {
-    const bool cv = ci < p.cval;
+    const bool cv = ci < p.cval && tap < taps;
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
       const bool v = bok[i] && cv;
@@ -338,7 +347,7 @@ __global__ __launch_bounds__(256) void conv_fwd32_kernel(IgemmArgs p) {
     brow[i] = p.b + (int64_t)(bok[i] ? co : 0) * taps * p.wcs;
   }
   locate_b();
-  const bool padded = p.c4 != p.cval;   // tap extent rounded up to 32: validity of a quad changes inside a tap
+  const bool padded = p.c4 != p.cval;   // tap extent rounded up: validity of a quad changes inside a tap
 
   f4 ra[AI], rb[BI];
   auto gload = [&]() {
@@ -347,16 +356,17 @@ __global__ __launch_bounds__(256) void conv_fwd32_kernel(IgemmArgs p) {
 #pragma unroll
     for (int i = 0; i < BI; ++i) rb[i] = ldg4(pb[i]);
     ci += 32;
-    const bool wrap = ci >= p.c4;   // wave-uniform (c4 is a multiple of 32)
-    if (wrap) {
+    bool moved = padded;
+    while (ci >= p.c4) {   // wave-uniform
       ci -= p.c4;
       ++tap;
       if (++kx == p.kw) {
         kx = 0;
         ++ky;
       }
+      moved = true;
     }
-    if (wrap || padded) {
+    if (moved) {
       locate();
       locate_b();
     } else {
@@ -398,7 +408,7 @@ __global__ __launch_bounds__(256) void conv_fwd32_kernel(IgemmArgs p) {
     }
   };
 
-  const int nk = p.K >> 5;   // K is a multiple of 32 on this path
+  const int nk = (p.K + 31) >> 5;   // a trailing half chunk reads zeros (tap >= taps)
   gload();
   sstore(0);
   __syncthreads();
@@ -943,8 +953,7 @@ int cat_conv2d_fwd(const cat_conv_t* g, const float* x, const float* w, const fl
   }
   // BK = 32 path: per-tap K extent a multiple of 32 (allowing <= 12.5 % zero padding) and float4-readable filter rows
   static const int no_bk32 = getenv("CAT_NO_BK32") ? atoi(getenv("CAT_NO_BK32")) : 0;
-  const int c32 = (a.cval + 31) & ~31;
-  const bool bk32 = !no_bk32 && a.wvec && (c32 - a.cval) * 8 <= c32 && !a.dbg;
+  const bool bk32 = !no_bk32 && a.wvec && (a.c4 & 15) == 0 && !a.dbg;   // a.c4 = walk_extent(cval): multiple of 16 when padding <= 12.5 %
 #define LAUNCH32(MT, NT, WM, WN)                                                                      \
   {                                                                                                   \
     cat::ProfScope prof("conv_fwd32_" #MT "x" #NT "x" #WM "x" #WN, prof_flops, 0.0, stream);          \
@@ -958,8 +967,6 @@ int cat_conv2d_fwd(const cat_conv_t* g, const float* x, const float* w, const fl
     conv_fwd32_kernel<MT, NT, WM, WN><<<grid, 256, lds, s>>>(a);                                       \
   }
   if (bk32) {
-    a.c4 = c32;
-    a.K = g->kh * g->kw * c32;
     DISPATCH_TILE_N(a.Cout, LAUNCH32);
   } else {
     DISPATCH_TILE_N(a.Cout, LAUNCH);

@@ -101,11 +101,51 @@ def _to_channels_last_(module):
         w.data = new
 
 
+def _folded_eval_bn(conv, bn, out_dim):
+    """Frozen-teacher fast path: conv -> BatchNorm2d(eval, running stats) is an affine map per output channel, so it is folded
+    into the conv's weight / bias once (cached until any of the tensors involved changes) and the norm kernel disappears.
+    One-time setup arithmetic, not part of the per-step kernel stream."""
+    tensors = [conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var]
+    key = tuple((t.data_ptr(), t._version) if t is not None else None for t in tensors)
+    cache = getattr(conv, '_cat_fold', None)
+    if cache is not None and cache[0] == key:
+        return cache[1], cache[2]
+    with torch.no_grad():
+        scale = torch.rsqrt(bn.running_var + bn.eps)
+        if bn.weight is not None:
+            scale = scale * bn.weight
+        shift = -bn.running_mean * scale
+        if bn.bias is not None:
+            shift = shift + bn.bias
+        shape = [1, 1, 1, 1]
+        shape[out_dim] = -1
+        w = conv.weight.detach()
+        if w.dim() == 4 and w.shape[1] > 1:
+            wf = ops.padded_weight_like(w.shape, w.device)
+            wf.copy_(w * scale.view(shape))
+        else:
+            wf = (w * scale.view(shape)).contiguous()
+        bf = shift if conv.bias is None else conv.bias.detach() * scale + shift
+        bf = bf.contiguous()
+    conv._cat_fold = (key, wf, bf)
+    return wf, bf
+
+
+def _bn_folds(bn):
+    return isinstance(bn, BatchNorm2d) and not bn.training and bn.track_running_stats and not torch.is_grad_enabled()
+
+
 class Conv2d(nn.Conv2d):
     """nn.Conv2d (dense or depthwise).  Weight storage is channels_last ([O][kh][kw][I]); state_dict values are
     unchanged (logical OIHW)."""
 
-    def forward(self, x, fuse_act=None):
+    def forward(self, x, fuse_act=None, fold_bn=None):
+        weight, bias = self.weight, self.bias
+        if fold_bn is not None:
+            weight, bias = _folded_eval_bn(self, fold_bn, 0)
+        return self._conv(x, weight, bias, fuse_act)
+
+    def _conv(self, x, weight, bias, fuse_act):
         pad, mode = self.padding[0], L.PAD_ZERO
         if isinstance(x, Padded):
             if pad != 0:
@@ -117,22 +157,28 @@ class Conv2d(nn.Conv2d):
             raise NotImplementedError('conv2d: use ReflectionPad2d for reflect padding (as the reference does)')
         act, slope = _act_code(fuse_act)
         if self.groups == 1:
-            _to_channels_last_(self)
-            return ops.Conv2dFn.apply(x, self.weight, self.bias, self.stride[0], pad, mode, act, slope)
+            if weight is self.weight:
+                _to_channels_last_(self)
+                weight = self.weight
+            return ops.Conv2dFn.apply(x, weight, bias, self.stride[0], pad, mode, act, slope)
         if self.groups == self.in_channels == self.out_channels and self.stride[0] == 1:
-            y = ops.DwConv2dFn.apply(x, self.weight, self.bias, pad, mode)
+            y = ops.DwConv2dFn.apply(x, weight, bias, pad, mode)
             return ops.ActFn.apply(y, act, slope) if act != L.ACT_NONE else y
         raise NotImplementedError('conv2d: groups must be 1 or == channels (depthwise, stride 1)')
 
 
 class ConvTranspose2d(nn.ConvTranspose2d):
-    def forward(self, x, fuse_act=None):
+    def forward(self, x, fuse_act=None, fold_bn=None):
         if isinstance(x, Padded):
             raise NotImplementedError('padding in front of a transposed conv')
         if self.groups != 1 or self.dilation != (1, 1) or self.stride[0] != self.stride[1] or self.padding[0] != self.padding[1]:
             raise NotImplementedError('conv_transpose2d: groups 1, dilation 1, square geometry only')
-        _to_channels_last_(self)
-        y = ops.ConvTranspose2dFn.apply(x, self.weight, self.bias, self.stride[0], self.padding[0], self.output_padding[0])
+        if fold_bn is not None:
+            weight, bias = _folded_eval_bn(self, fold_bn, 1)
+        else:
+            _to_channels_last_(self)
+            weight, bias = self.weight, self.bias
+        y = ops.ConvTranspose2dFn.apply(x, weight, bias, self.stride[0], self.padding[0], self.output_padding[0])
         if fuse_act is not None:
             act, slope = _act_code(fuse_act)
             y = ops.ActFn.apply(y, act, slope)
@@ -158,7 +204,9 @@ class _NormMixin:
 
 
 class BatchNorm2d(_NormMixin, nn.BatchNorm2d):
-    def forward(self, x, fuse_act=None):
+    def forward(self, x, fuse_act=None, applied=False):
+        if applied:      # folded into the preceding conv (eval mode); called only so that forward hooks fire
+            return x
         use_batch = self.training or not self.track_running_stats
         return self._run(x, L.NORM_BATCH, use_batch, fuse_act)
 
@@ -183,7 +231,16 @@ class FusedSequential(nn.Sequential):
         while i < n:
             m = mods[i]
             nxt = mods[i + 1] if i + 1 < n else None
-            if isinstance(m, _FUSABLE) and isinstance(nxt, _ACTS):
+            if isinstance(m, (Conv2d, ConvTranspose2d)) and _bn_folds(nxt):
+                # frozen network in eval mode: conv + BatchNorm(running stats) [+ activation] = ONE conv kernel
+                act = mods[i + 2] if i + 2 < n and isinstance(mods[i + 2], _ACTS) else None
+                x = m(x, fuse_act=act, fold_bn=nxt)
+                x = nxt(x, applied=True)
+                i += 2
+                if act is not None:
+                    x = act(x, applied=True)
+                    i += 1
+            elif isinstance(m, _FUSABLE) and isinstance(nxt, _ACTS):
                 x = m(x, fuse_act=nxt)
                 x = nxt(x, applied=True)
                 i += 2
