@@ -868,6 +868,32 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }                                \
   } while (0)
 
+// Few output pixels (e.g. the student's 64x64 trunk at batch 16 = 256 tiles of 256 rows): halve the M tile so that every CU
+// holds 2+ workgroups and the per-chunk load / LDS / barrier latencies of one overlap the MFMA stream of another.
+#define DISPATCH_TILE_N_SMALLM(n, LAUNCH) \
+  do {                               \
+    if ((n) <= 16) {                 \
+      LAUNCH(2, 1, 4, 1);            \
+    } else if ((n) <= 32) {          \
+      LAUNCH(2, 2, 4, 1);            \
+    } else if ((n) <= 48) {          \
+      LAUNCH(1, 3, 4, 1);            \
+    } else if ((n) <= 64) {          \
+      LAUNCH(1, 4, 4, 1);            \
+    } else if ((n) <= 96) {          \
+      LAUNCH(1, 6, 4, 1);            \
+    } else {                         \
+      LAUNCH(4, 4, 2, 2);            \
+    }                                \
+  } while (0)
+
+static int default_bm(int n) { return n <= 32 ? 256 : 128; }
+static bool use_small_m(int M, int n) {
+  static const int mode = getenv("CAT_SMALLM") ? atoi(getenv("CAT_SMALLM")) : 1;
+  if (!mode || n > 32) return false;   // measured: helps the 16/32-wide tiles (256-row default), not the 48..96-wide ones
+  return cdiv(M, default_bm(n)) < 768;
+}
+
 int fill_common(IgemmArgs& a, const cat_conv_t* g) {
   CAT_REQUIRE(g->N > 0 && g->H > 0 && g->W > 0 && g->Cin > 0 && g->Cout > 0, "conv: empty geometry");
   CAT_REQUIRE(g->stride == 1 || g->stride == 2, "conv: stride %d unsupported", g->stride);
@@ -966,10 +992,13 @@ int cat_conv2d_fwd(const cat_conv_t* g, const float* x, const float* w, const fl
     }                                                                                                 \
     conv_fwd32_kernel<MT, NT, WM, WN><<<grid, 256, lds, s>>>(a);                                       \
   }
+  const bool smallm = use_small_m(a.M, a.Cout);
   if (bk32) {
-    DISPATCH_TILE_N(a.Cout, LAUNCH32);
+    if (smallm) DISPATCH_TILE_N_SMALLM(a.Cout, LAUNCH32);
+    else DISPATCH_TILE_N(a.Cout, LAUNCH32);
   } else {
-    DISPATCH_TILE_N(a.Cout, LAUNCH);
+    if (smallm) DISPATCH_TILE_N_SMALLM(a.Cout, LAUNCH);
+    else DISPATCH_TILE_N(a.Cout, LAUNCH);
   }
 #undef LAUNCH32
   if (a.dbg) {
@@ -1007,7 +1036,8 @@ int cat_conv2d_dgrad(const cat_conv_t* g, const float* dy, const float* w, const
     dim3 grid(cdiv(mmax, WM * MT * 16) * cdiv(a.Cin, WN * NT * 16), st * st);              \
     conv_dgrad_kernel<MT, NT, WM, WN><<<grid, 256, 0, s>>>(a);                              \
   }
-  DISPATCH_TILE_N(a.Cin, LAUNCH);
+  if (use_small_m(mmax, a.Cin)) DISPATCH_TILE_N_SMALLM(a.Cin, LAUNCH);
+  else DISPATCH_TILE_N(a.Cin, LAUNCH);
 #undef LAUNCH
   return cat::check_launch("conv2d_dgrad");
 }
