@@ -146,7 +146,11 @@ class InvertedResidualChannels(nn.Module):
             return x
         # one alias of x per consumer (branches + residual); their gradients are summed by one add_n kernel
         xs = ops.fanout(x, nb + 1)
-        branches = [op(xi) for op, xi in zip(list(self.res_ops) + list(self.dw_ops), xs[:nb])]
+        branch_ops = list(self.res_ops) + list(self.dw_ops)
+        if ops.branch_streams_enabled() and x.is_cuda and nb > 1:
+            branches = ops.run_on_side_streams(branch_ops, xs[:nb])
+        else:
+            branches = [op(xi) for op, xi in zip(branch_ops, xs[:nb])]
         tmp = branches[0] if nb == 1 else ops.AddNFn.apply(*branches)
         tmp = self.pw_bn(tmp)
         return ops.AddNFn.apply(xs[nb], tmp)

@@ -5,6 +5,7 @@ layout [N][H][W][cs] with cs = round_up(C, 4) floats per pixel and zero padding 
 device memory, the stream and the autograd tape; every arithmetic op below is a HIP kernel of libcat_hip.so and
 raises if the library is missing (no eager / CPU fallback)."""
 import ctypes as C
+import os
 import warnings
 
 import torch
@@ -71,6 +72,44 @@ def workspace(nbytes, device):
         buf = torch.empty((max(nbytes, 1 << 20) + 3) // 4, device=device, dtype=torch.float32)
         _WS[key] = buf
     return buf
+
+
+# ---------------------------------------------------------------------------------------------- branch-level concurrency
+# The 6 branches of an InvertedResidualChannels block are independent chains of small kernels (64x64 pixels x 6..42 channels): each
+# one alone cannot fill 256 CUs.  Running them on separate HIP streams lets the hardware overlap their launches, tails and
+# latency-bound phases; autograd replays every backward node on the stream its forward ran on, so the backward overlaps too.
+_SIDE = {}
+_BRANCH_STREAMS = os.environ.get('CAT_BRANCH_STREAMS', '1') != '0'
+
+
+def branch_streams_enabled():
+    return _BRANCH_STREAMS
+
+
+def set_branch_streams(on):
+    global _BRANCH_STREAMS
+    _BRANCH_STREAMS = bool(on)
+
+
+def run_on_side_streams(fns, inputs):
+    main = torch.cuda.current_stream()
+    dev = inputs[0].device
+    key = (dev, main.cuda_stream)
+    pool = _SIDE.get(key)
+    if pool is None or len(pool) < len(fns):
+        pool = [torch.cuda.Stream(device=dev) for _ in range(max(len(fns), 6))]
+        _SIDE[key] = pool
+    fork = main.record_event()
+    outs = []
+    for fn, xi, st in zip(fns, inputs, pool):
+        st.wait_event(fork)
+        xi.record_stream(st)
+        with torch.cuda.stream(st):
+            o = fn(xi)
+        o.record_stream(main)
+        main.wait_event(st.record_event())
+        outs.append(o)
+    return outs
 
 
 def to_nhwc(x):
@@ -478,6 +517,10 @@ class FanoutFn(torch.autograd.Function):
         dys = [conform(d) for d in dys if d is not None]
         if not dys:
             return None, None
+        if _BRANCH_STREAMS:
+            cur = torch.cuda.current_stream()
+            for d in dys:
+                d.record_stream(cur)       # produced on a branch stream, consumed (and freed) here
         if len(dys) == 1:
             return dys[0], None
         n, c, h, w = dys[0].shape
