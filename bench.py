@@ -11,8 +11,8 @@ weights of the named architecture, fp32 everywhere.  Data parallel = one process
 per-GPU batch fixed), RCCL all-reduce of the gradient buckets.
 
 The JSON line carries `roofline` for the dominant kernel family (the fp32-MFMA implicit-GEMM convolutions; achieved =
-algorithmic FLOPs / HIP-event time of those launches, measured in a short pass after the timed region so the events do
-not perturb `value`) and `cpu_baseline` (the CPU oracle timed on a bounded sample of the same workload on rank 0)."""
+algorithmic FLOPs / HIP-event time of those launches, measured in a short SERIAL pass after the timed region -- stream-level
+concurrency off -- so the events neither perturb `value` nor see co-running kernels) and `cpu_baseline` (the CPU oracle timed on a bounded sample of the same workload on rank 0)."""
 import argparse
 import json
 import os
@@ -107,6 +107,8 @@ def main():
     torch.cuda.set_device(local)
     from oracle import detfill
     model, opt = build_model(args, local)
+    if args.no_overlap:
+        model.teacher_side_stream = False
     if world > 1:
         model.enable_data_parallel(parallel.DataParallelReducer(), overlap=not args.no_overlap)
 
@@ -176,13 +178,23 @@ def kernel_roofline(model, step, args):
     if not hasattr(lib, 'cat_prof_enable'):
         return None
     import ctypes as C
+    from cat_amd import ops
     nsteps = 2
+    # kernels are timed one at a time: the stream-level concurrency used in the timed region (block branches and the teacher on
+    # side streams) is switched off here, otherwise co-running kernels share the chip and every per-kernel duration is inflated
+    was_branch, was_teacher = ops.branch_streams_enabled(), getattr(model, 'teacher_side_stream', False)
+    ops.set_branch_streams(False)
+    model.teacher_side_stream = False
+    step(9_999)
+    torch.cuda.synchronize()
     lib.cat_prof_enable(1)
     for i in range(nsteps):
         step(10_000 + i)
     torch.cuda.synchronize()
     n = lib.cat_prof_collect()
     lib.cat_prof_enable(0)
+    ops.set_branch_streams(was_branch)
+    model.teacher_side_stream = was_teacher
     fams = {}
     name = C.create_string_buffer(64)
     cnt, ms, fl = C.c_int64(), C.c_double(), C.c_double()

@@ -95,9 +95,26 @@ class InceptionDistiller(BaseInceptionDistiller):
         torch.autograd.backward(terms, seeds)
 
     def optimize_parameters(self, steps):
+        """forward -> D step -> G step (inception_distiller.py:179-188).  Optionally (`teacher_side_stream`) the frozen teacher's
+        forward -- which depends on no trainable state -- runs on a side stream while the main stream does the student forward and
+        the discriminator step; the streams join before backward_G reads the teacher's activations.  Off by default on one GPU;
+        the data-parallel schedule (_optimize_parameters_dp) uses it to hide the gradient all-reduces."""
         if self.dp is not None and getattr(self, 'dp_overlap', True):
-            return self._optimize_parameters_overlapped(steps)
-        self.forward()
+            return self._optimize_parameters_dp(steps)
+        overlap = getattr(self, 'teacher_side_stream', False)   # measured on 1 GPU: -2 % (two MFMA-bound streams only contend)
+        if overlap:
+            main = torch.cuda.current_stream(self.device)
+            if getattr(self, '_side_stream', None) is None:
+                self._side_stream = torch.cuda.Stream(device=self.device)
+            side = self._side_stream
+            side.wait_stream(main)
+            self.real_A.record_stream(side)
+            with torch.cuda.stream(side), torch.no_grad():
+                self.Tfake_B = self.netG_teacher(self.real_A)
+            t_done = side.record_event()
+            self.Sfake_B = self.netG_student(self.real_A)
+        else:
+            self.forward()
         self.set_requires_grad(self.netD, True)
         self.optimizer_D.zero_grad()
         self.backward_D()
@@ -106,6 +123,10 @@ class InceptionDistiller(BaseInceptionDistiller):
         self.optimizer_D.step()
         self.set_requires_grad(self.netD, False)
         self.optimizer_G.zero_grad()
+        if overlap:
+            main.wait_event(t_done)
+            for t in [self.Tfake_B] + list(self.Tacts.values()):
+                t.record_stream(main)
         self.backward_G(steps)
         if self.dp is not None:
             self.dp.reduce(self.optimizer_G)
@@ -117,7 +138,8 @@ class InceptionDistiller(BaseInceptionDistiller):
         self.dp = reducer
         self.dp_overlap = overlap
         self._pending_G = None
-        self._side_stream = torch.cuda.Stream(device=self.device)
+        if getattr(self, '_side_stream', None) is None:
+            self._side_stream = torch.cuda.Stream(device=self.device)
         reducer.broadcast_parameters([self.netG_teacher, self.netG_student, self.netD] + list(self.netAs))
 
     def finish_pending(self):
@@ -127,7 +149,7 @@ class InceptionDistiller(BaseInceptionDistiller):
             self.optimizer_G.step()
             self._pending_G = None
 
-    def _optimize_parameters_overlapped(self, steps):
+    def _optimize_parameters_dp(self, steps):
         """Same arithmetic as optimize_parameters, scheduled for xGMI overlap:
           side stream : frozen-teacher forward of THIS batch
           main stream : [wait G all-reduce of the previous step -> Adam G] -> student forward -> D step (D bucket
@@ -135,6 +157,7 @@ class InceptionDistiller(BaseInceptionDistiller):
         main = torch.cuda.current_stream(self.device)
         side = self._side_stream
         side.wait_stream(main)
+        self.real_A.record_stream(side)
         with torch.cuda.stream(side), torch.no_grad():
             self.Tfake_B = self.netG_teacher(self.real_A)
         t_done = side.record_event()
