@@ -170,6 +170,22 @@ def main():
         torch.distributed.destroy_process_group()
 
 
+def pmc_traffic(family):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
+    (profiles/r01_d_pmc_hbm.json: FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled per the gfx950 note in
+    MI355X_MICROARCH.md §HBM).  PMC collection cannot run inside the timed process, hence the lookup; None if absent."""
+    path = os.path.join(ROOT, 'profiles', 'r01_d_pmc_hbm.json')
+    if not os.path.exists(path):
+        return None
+    parts = family.split('_')                      # conv_fwd32_4x4x2x2 -> conv_fwd32_kernel<4, 4, 2, 2>
+    key = '_'.join(parts[:-1]) + '_kernel<' + ', '.join(parts[-1].split('x')) + '>'
+    table = json.load(open(path))
+    for k, v in table.items():
+        if k.startswith(key[:-1]):
+            return v.get('hbm_bytes_per_launch')
+    return None
+
+
 def kernel_roofline(model, step, args):
     """HIP-event timing of every implicit-GEMM conv launch (events recorded on the launch stream by libcat_hip's
     profiling hook) over a few extra steps; achieved = algorithmic conv FLOPs / summed kernel time."""
@@ -211,7 +227,7 @@ def kernel_roofline(model, step, args):
     d = conv[dom]
     achieved = d['gflop_per_step'] / d['ms_per_step'] if d['ms_per_step'] > 0 else 0.0   # GFLOP/ms == TFLOP/s
     return {'bound': 'mfma', 'kernel': dom, 'achieved': round(achieved, 3), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-            'frac': round(achieved / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': None,
+            'frac': round(achieved / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': pmc_traffic(dom),
             'avg_launch_us': round(1e3 * d['ms_per_step'] / max(d['launches_per_step'], 1), 3),
             'all_conv': {'achieved': round(tot_gf / tot_ms, 3) if tot_ms else 0.0, 'ms_per_step': round(tot_ms, 3),
                          'gflop_per_step': round(tot_gf, 2)},
