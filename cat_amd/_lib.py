@@ -11,6 +11,7 @@ c_f = C.c_float
 c_i = C.c_int
 c_l = C.c_int64
 c_p = C.c_void_p
+c_d = C.c_double
 
 
 class ConvGeom(C.Structure):
@@ -69,6 +70,24 @@ SIGNATURES = {
     'cat_prof_family_bytes': (C.c_double, [c_i]),
     'cat_fill': (c_i, [c_p, c_l, c_f, c_p]),
     'cat_axpy': (c_i, [c_p, c_p, c_l, c_f, c_p]),
+    'cat_bn_ws_bytes': (C.c_size_t, [c_l, c_i]),
+    'cat_bn_stats_fwd': (c_i, [c_p, c_l, c_i, c_i, c_p, c_p, c_p]),
+    'cat_bn_finalize': (c_i, [c_p, c_d, c_i, c_i, c_f, c_i, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    'cat_bn_stats_bwd': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_f, c_p, c_p, c_p]),
+    'cat_bn_apply_bwd': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_d, c_p, c_p, c_p, c_p, c_i, c_l, c_i, c_i, c_i, c_f, c_p]),
+    'cat_spade_fwd': (c_i, [c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_i, c_f, c_p]),
+    'cat_spade_bwd_stats': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_i, c_f, c_p, c_p]),
+    'cat_spade_bwd_apply': (c_i, [c_p, c_p, c_p, c_p, c_d, c_p, c_l, c_i, c_i, c_p]),
+    'cat_interp_nearest_fwd': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    'cat_upsample_nearest_bwd': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    'cat_avgpool3x3s2_fwd': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
+    'cat_avgpool3x3s2_bwd': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
+    'cat_maxpool2x2_fwd': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
+    'cat_maxpool2x2_bwd': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
+    'cat_onehot_edges': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
+    'cat_spectral_norm_ws_bytes': (C.c_size_t, [c_i, c_i, c_i, c_i]),
+    'cat_spectral_norm_fwd': (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_f, c_p, c_p, c_p, c_p, c_p]),
+    'cat_spectral_norm_bwd': (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p]),
 }
 
 _lib = None

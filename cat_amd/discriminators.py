@@ -1,9 +1,13 @@
-"""PatchGAN discriminator, reference models/modules/discriminators.py:14-79 (same `model.{i}` state_dict keys)."""
+"""PatchGAN discriminators, reference models/modules/discriminators.py:14-79 (NLayer, `model.{i}` state_dict keys) and :129-226
+(SPADENLayer / Multiscale, `discriminator_{i}.model{j}` keys)."""
 import functools
 
+import numpy as np
+import torch
 from torch import nn
 
 from . import nn as cnn
+from . import ops
 from .inception_generator import BaseNetwork
 from .inception_modules import get_active_fn
 
@@ -33,3 +37,72 @@ class NLayerDiscriminator(BaseNetwork):
 
     def forward(self, input):
         return self.model(input)
+
+
+class SPADENLayerDiscriminator(BaseNetwork):
+    """reference discriminators.py:129-182: `model{i}` children; forward returns every intermediate output."""
+
+    @staticmethod
+    def modify_commandline_options(parser, is_train):
+        return parser
+
+    def __init__(self, opt):
+        super().__init__()
+        from .normalization import get_nonspade_norm_layer
+        self.opt = opt
+        kw = 4
+        padw = int(np.ceil((kw - 1.0) / 2))
+        nf = opt.ndf
+        input_nc = self.compute_D_input_nc(opt)
+        norm_layer = get_nonspade_norm_layer(opt, opt.norm_D)
+        sequence = [[cnn.Conv2d(input_nc, nf, kernel_size=kw, stride=2, padding=padw), cnn.LeakyReLU(0.2, False)]]
+        for n in range(1, opt.n_layers_D):
+            nf_prev = nf
+            nf = min(nf * 2, 512)
+            stride = 1 if n == opt.n_layers_D - 1 else 2
+            sequence += [[norm_layer(cnn.Conv2d(nf_prev, nf, kernel_size=kw, stride=stride, padding=padw)), cnn.LeakyReLU(0.2, False)]]
+        sequence += [[cnn.Conv2d(nf, 1, kernel_size=kw, stride=1, padding=padw)]]
+        for n in range(len(sequence)):
+            self.add_module('model' + str(n), cnn.FusedSequential(*sequence[n]))
+
+    def compute_D_input_nc(self, opt):
+        return opt.semantic_nc + opt.output_nc
+
+    def forward(self, input):
+        results = [input]
+        for submodel in self.children():
+            results.append(submodel(results[-1]))
+        return results[1:]
+
+
+class MultiscaleDiscriminator(nn.Module):
+    """reference discriminators.py:185-226: num_D PatchGANs on an average-pooled pyramid of the input."""
+
+    @staticmethod
+    def modify_commandline_options(parser, is_train):
+        parser.add_argument('--num_D', type=int, default=2, help='number of discriminators to be used in multiscale')
+        parser.add_argument('--norm_D', type=str, default='spectralinstance', help='instance normalization or batch normalization')
+        parser.set_defaults(n_layers_D=4)
+        return parser
+
+    def __init__(self, opt):
+        super().__init__()
+        self.opt = opt
+        for i in range(opt.num_D):
+            self.add_module('discriminator_%d' % i, SPADENLayerDiscriminator(opt))
+
+    def downsample(self, input):
+        return ops.AvgPool3x3s2Fn.apply(input)
+
+    def forward(self, input):
+        result = []
+        nd = len(self._modules)
+        for i, (name, D) in enumerate(self.named_children()):
+            if i + 1 < nd and input.requires_grad and torch.is_grad_enabled():
+                cur, nxt = ops.fanout(input, 2)
+            else:
+                cur = nxt = input
+            result.append(D(cur))
+            if i + 1 < nd:              # the reference also pools after the last scale; the result is unused
+                input = self.downsample(nxt)
+        return result

@@ -3,7 +3,9 @@ the reference's models/modules/inception_modules.py:12-243 (get_active_fn, ConvB
 built from cat_amd.nn layers so every op is a gfx950 kernel."""
 import collections
 import functools
+import re
 
+import torch
 from torch import nn
 
 from . import nn as cnn
@@ -161,10 +163,314 @@ class InvertedResidualChannels(nn.Module):
             self.dw_kernel_sizes)
 
 
-def _get_named_block_list(m):
-    """Get `{name: module}` dictionary for inverted residual blocks (reference inception_modules.py `_get_named_block_list`)."""
-    blocks = list(m.features.named_children())
-    all_blocks = []
-    for name, block in blocks:
-        all_blocks.append(('features.{}'.format(name), block))
-    return collections.OrderedDict(all_blocks)
+def _get_named_block_list(m, spade=False, num_upsampling_layers=None):
+    """Get `{name: module}` dictionary for inverted residual blocks (reference inception_modules.py:260-277)."""
+    if spade:
+        blocks = [('head_0', m.head_0)]
+        blocks += [(f'G_middle_{i}', getattr(m, f'G_middle_{i}')) for i in range(2)]
+        blocks += [(f'up_{i}', getattr(m, f'up_{i}')) for i in range(4)]
+        if num_upsampling_layers == 'most':
+            blocks += [('up_4', m.up_4)]
+        return collections.OrderedDict(blocks)
+    return collections.OrderedDict(('features.{}'.format(name), block) for name, block in m.features.named_children())
+
+
+def output_network(model):
+    """Output network kwargs in `searched_network` style (reference inception_modules.py:246-258)."""
+    res = []
+    for block in model.get_named_block_list().values():
+        res.append([block.input_dim, block.res_channels, block.dw_channels, block.res_kernel_sizes, block.dw_kernel_sizes,
+                    getattr(block, 'stride', 1)])
+    return {'inverted_residual_setting': res}
+
+
+# ------------------------------------------------------------------------------------------------ GauGAN / SPADE blocks
+def _branch_channels(channels, default, factor, kernel_sizes):
+    if channels is None:
+        return [default // factor for _ in kernel_sizes]
+    if type(channels) == int:
+        return [channels // factor for _ in kernel_sizes]
+    assert len(channels) == len(kernel_sizes)
+    return [c // factor for c in channels]
+
+
+class ConvSyncBNReLU(nn.Module):
+    """Conv2d(pad same) -> norm -> activation with sub-modules `conv`, `norm`, `active` (reference inception_modules.py:280-313).
+    Train mode: conv kernel + split-phase batch norm with the activation fused into its apply pass; frozen (eval, no grad):
+    the running statistics are folded into the conv and the whole thing is ONE kernel."""
+
+    def __init__(self, in_planes, out_planes, kernel_size=3, stride=1, groups=1, use_bias=True, norm_layer=None, active_fn=None,
+                 spectral_norm=False, spade=False):
+        super().__init__()
+        self.conv = cnn.Conv2d(in_planes, out_planes, kernel_size, stride, (kernel_size - 1) // 2, groups=groups, bias=use_bias)
+        self.norm = norm_layer(norm_nc=out_planes) if spade else norm_layer(out_planes)
+        self.active = active_fn()
+        if spectral_norm:
+            self.conv = cnn.spectral_norm(self.conv)
+
+    def forward(self, x, seg=None):
+        if seg is not None:
+            return self.active(self.norm(self.conv(x), seg))
+        if cnn._bn_folds(self.norm) and 'weight_orig' not in self.conv._parameters:
+            y = self.conv(x, fuse_act=self.active, fold_bn=self.norm)
+            return self.active(self.norm(y, applied=True), applied=True)
+        y = self.norm(self.conv(x), fuse_act=self.active)
+        return self.active(y, applied=True)
+
+    def remove_spectral_norm(self):
+        raise NotImplementedError('remove_spectral_norm belongs to the export path (out of scope)')
+
+
+class Conv(nn.Module):
+    """Convolution with "same" padding (reference inception_modules.py:316-341)."""
+
+    def __init__(self, in_planes, out_planes, kernel_size=3, stride=1, groups=1, use_bias=True, spectral_norm=False):
+        super().__init__()
+        self.conv = cnn.Conv2d(in_planes, out_planes, kernel_size, stride, (kernel_size - 1) // 2, groups=groups, bias=use_bias)
+        if spectral_norm:
+            self.conv = cnn.spectral_norm(self.conv)
+
+    def forward(self, x):
+        return self.conv(x)
+
+
+def _run_branches(branch_ops, x, extra=()):
+    """sum of the (independent) branches applied to x, plus `extra` addends, in ONE add_n kernel; the branches run on side HIP
+    streams (ops.run_on_side_streams) so their small kernels overlap."""
+    nb = len(branch_ops)
+    xs = ops.fanout(x, nb) if x.requires_grad and torch.is_grad_enabled() else [x] * nb
+    if ops.branch_streams_enabled() and x.is_cuda and nb > 1:
+        outs = ops.run_on_side_streams(branch_ops, xs)
+    else:
+        outs = [op(xi) for op, xi in zip(branch_ops, xs)]
+    outs = list(outs) + list(extra)
+    return outs[0] if len(outs) == 1 else ops.AddNFn.apply(*outs)
+
+
+def seg_at(segmap, size):
+    """F.interpolate(segmap, size, mode='nearest') (inception_modules.py:748), computed once per (segmap, resolution): every SPADE
+    layer of the teacher AND the student that runs at this resolution shares the result."""
+    size = (int(size[0]), int(size[1]))
+    if tuple(segmap.shape[2:]) == size:
+        return segmap
+    cache = getattr(segmap, '_cat_pyramid', None)
+    if cache is None or cache[0] != segmap._version:
+        cache = (segmap._version, {})
+        segmap._cat_pyramid = cache
+    out = cache[1].get(size)
+    if out is None:
+        with torch.no_grad():
+            out = ops.interp_nearest(segmap, size)
+        cache[1][size] = out
+    return out
+
+
+class InceptionSPADE(nn.Module):
+    """SPADE with inception-style gamma/beta branches (reference inception_modules.py:564-769):
+    out = param_free_norm(x) * (1 + gamma) + beta, [gamma | beta] = sum_k res_k(seg) + sum_k dw_k(seg)."""
+
+    def __init__(self, norm, norm_nc, label_nc, nhidden=128, opt=None):
+        super(InceptionSPADE, self).__init__()
+        res_kernel_sizes = opt.kernel_sizes
+        dw_kernel_sizes = opt.kernel_sizes
+        if type(res_kernel_sizes) == int:
+            res_kernel_sizes = dw_kernel_sizes = [res_kernel_sizes]
+        self.norm_layer = functools.partial(cnn.SynchronizedBatchNorm2d, affine=True)
+        self.active_fn = functools.partial(cnn.ReLU, inplace=True)
+        self.param_free_norm_layer = norm
+        self.input_dim = label_nc
+        self.output_dim = norm_nc
+        self.res_channels = _branch_channels(opt.channels, nhidden, opt.channels_reduction_factor, res_kernel_sizes)
+        self.dw_channels = _branch_channels(opt.channels, nhidden, opt.channels_reduction_factor, dw_kernel_sizes)
+        self.res_kernel_sizes = res_kernel_sizes
+        self.dw_kernel_sizes = dw_kernel_sizes
+        self.param_free_norm, self.res_ops, self.dw_ops = self._build()
+
+    def _build(self):
+        param_free_norm = self.param_free_norm_layer(self.output_dim, affine=False)
+        res_ops = nn.ModuleList()
+        for midp, k in zip(self.res_channels, self.res_kernel_sizes):
+            if midp == 0:
+                continue
+            res_ops.append(nn.Sequential(
+                ConvSyncBNReLU(self.input_dim, midp, kernel_size=k, norm_layer=self.norm_layer, active_fn=self.active_fn),
+                cnn.Conv2d(midp, 2 * self.output_dim, kernel_size=k, padding=(k - 1) // 2)))
+        dw_ops = nn.ModuleList()
+        for midp, k in zip(self.dw_channels, self.dw_kernel_sizes):
+            if midp == 0:
+                continue
+            dw_ops.append(nn.Sequential(
+                ConvSyncBNReLU(self.input_dim, midp, kernel_size=1, norm_layer=self.norm_layer, active_fn=self.active_fn),
+                ConvSyncBNReLU(midp, midp, kernel_size=k, groups=midp, norm_layer=self.norm_layer, active_fn=self.active_fn),
+                cnn.Conv2d(midp, 2 * self.output_dim, kernel_size=1)))
+        return param_free_norm, res_ops, dw_ops
+
+    def get_first_res_bn(self):
+        return list(self.get_named_first_res_bn().values())
+
+    def get_first_dw_bn(self):
+        return list(self.get_named_first_dw_bn().values())
+
+    def get_first_bn(self):
+        return self.get_first_res_bn() + self.get_first_dw_bn()
+
+    def get_named_first_res_bn(self, prefix=None):
+        res = collections.OrderedDict()
+        for i, op in enumerate(self.res_ops):
+            assert isinstance(op[0], ConvSyncBNReLU)
+            res[add_prefix(f'res_ops.{i}.0.norm', prefix)] = op[0].norm
+        return res
+
+    def get_named_first_dw_bn(self, prefix=None):
+        res = collections.OrderedDict()
+        for i, op in enumerate(self.dw_ops):
+            assert isinstance(op[0], ConvSyncBNReLU)
+            res[add_prefix(f'dw_ops.{i}.0.norm', prefix)] = op[0].norm
+        return res
+
+    def get_named_first_bn(self, prefix=None):
+        return collections.OrderedDict(list(self.get_named_first_res_bn().items()) + list(self.get_named_first_dw_bn().items()))
+
+    def forward(self, x, segmap, fuse_act=None):
+        """`fuse_act`: the activation SPADEInvertedResidualChannels applies right after (inception_modules.py:553), fused here."""
+        pfn = self.param_free_norm
+        if not isinstance(pfn, cnn.BatchNorm2d):
+            raise NotImplementedError('SPADE param-free norm: (sync)batch only -- the distillation scripts use spadesyncbatch3x3')
+        act, slope = cnn._act_code(fuse_act)
+        seg = seg_at(segmap, x.shape[2:])
+        branch_ops = list(self.res_ops) + list(self.dw_ops)
+        if not branch_ops:      # gamma = beta = 0: the plain param-free norm
+            return pfn(x, fuse_act=fuse_act)
+        gb = _run_branches(branch_ops, seg)
+        if pfn.training or not pfn.track_running_stats:
+            track = pfn.training and pfn.track_running_stats
+            return ops.SpadeFn.apply(x, gb, pfn.running_mean if track else None, pfn.running_var if track else None, float(pfn.eps),
+                                     float(pfn.momentum), act, slope)
+        return ops.spade_eval(x, gb, pfn.running_mean, pfn.running_var, float(pfn.eps), act, slope)
+
+    def __repr__(self):
+        return ('{}({}, {}, res_channels={}, dw_channels={}, res_kernel_sizes={}, dw_kernel_sizes={})').format(
+            self._get_name(), self.input_dim, self.input_dim, self.res_channels, self.dw_channels, self.res_kernel_sizes,
+            self.dw_kernel_sizes)
+
+
+class SPADEInvertedResidualChannels(nn.Module):
+    """act(SPADE(x, seg)) -> sum_k res_k + sum_k dw_k, plus (learned) shortcut (reference inception_modules.py:344-562)."""
+
+    def __init__(self, fin, fout, opt):
+        super().__init__()
+        self.opt = opt
+        self.learned_shortcut = (fin != fout)
+        fmiddle = min(fin, fout)
+        res_kernel_sizes = opt.kernel_sizes
+        dw_kernel_sizes = opt.kernel_sizes
+        if type(res_kernel_sizes) == int:
+            res_kernel_sizes = dw_kernel_sizes = [res_kernel_sizes]
+        self.input_dim = fin
+        self.output_dim = fout
+        self.res_channels = _branch_channels(opt.channels, fmiddle, opt.channels_reduction_factor, res_kernel_sizes)
+        self.dw_channels = _branch_channels(opt.channels, fmiddle, opt.channels_reduction_factor, dw_kernel_sizes)
+        self.res_kernel_sizes = res_kernel_sizes
+        self.dw_kernel_sizes = dw_kernel_sizes
+        self.active_fn = get_active_fn(opt.active_fn)
+        self.active = self.active_fn()
+        self.spectral_norm = 'spectral' in opt.norm_G
+        spade_config_str = opt.norm_G.replace('spectral', '')
+        if not spade_config_str.startswith('spade'):
+            raise NotImplementedError
+        parsed = re.search(r'spade(\D+)(\d)x\d', spade_config_str)
+        param_free_norm_type = str(parsed.group(1))
+        self.spade_norm = InceptionSPADE
+        if param_free_norm_type == 'syncbatch':
+            self.norm_layer = cnn.SynchronizedBatchNorm2d
+        elif param_free_norm_type == 'batch':
+            self.norm_layer = cnn.BatchNorm2d
+        elif param_free_norm_type == 'instance':
+            raise NotImplementedError('spadeinstance: the distillation scripts use spadesyncbatch3x3 (SURVEY §8a A15)')
+        else:
+            raise ValueError(f'{param_free_norm_type} is not a recognized param-free norm type in SPADE')
+        self.semantic_nc = opt.semantic_nc
+        self.res_ops, self.dw_ops, self.shortcut, self.spade = self._build()
+
+    def _build(self, build_only=False):
+        sn = self.spectral_norm
+        res_ops = nn.ModuleList()
+        for midp, k in zip(self.res_channels, self.res_kernel_sizes):
+            if midp == 0:
+                continue
+            res_ops.append(nn.Sequential(
+                ConvSyncBNReLU(self.input_dim, midp, kernel_size=k, norm_layer=functools.partial(self.norm_layer, affine=True),
+                               active_fn=self.active_fn, spectral_norm=sn),
+                Conv(midp, self.output_dim, kernel_size=k, spectral_norm=sn)))
+        dw_ops = nn.ModuleList()
+        for midp, k in zip(self.dw_channels, self.dw_kernel_sizes):
+            if midp == 0:
+                continue
+            dw_ops.append(nn.Sequential(
+                ConvSyncBNReLU(self.input_dim, midp, kernel_size=1, norm_layer=functools.partial(self.norm_layer, affine=True),
+                               active_fn=self.active_fn, spectral_norm=sn),
+                ConvSyncBNReLU(midp, midp, kernel_size=k, groups=midp, norm_layer=functools.partial(self.norm_layer, affine=False),
+                               active_fn=self.active_fn, spectral_norm=sn),
+                Conv(midp, self.output_dim, kernel_size=1, spectral_norm=sn)))
+        if self.learned_shortcut:
+            shortcut = nn.Sequential(self.norm_layer(self.input_dim, affine=True),
+                                     Conv(self.input_dim, self.output_dim, kernel_size=1, use_bias=False, spectral_norm=sn))
+        else:
+            shortcut = None
+        if build_only:
+            self.spade.param_free_norm, self.spade.res_ops, self.spade.dw_ops = self.spade._build()
+            spade = self.spade
+        else:
+            spade = self.spade_norm(norm=self.norm_layer, norm_nc=self.input_dim, label_nc=self.semantic_nc, opt=self.opt)
+        return res_ops, dw_ops, shortcut, spade
+
+    def get_first_res_bn(self):
+        return list(self.get_named_first_res_bn().values())
+
+    def get_first_dw_bn(self):
+        return list(self.get_named_first_dw_bn().values())
+
+    def get_first_bn(self):
+        return self.get_first_res_bn() + self.get_first_dw_bn()
+
+    def get_named_first_res_bn(self, prefix=None):
+        res = collections.OrderedDict()
+        for i, op in enumerate(self.res_ops):
+            assert isinstance(op[0], ConvSyncBNReLU)
+            assert isinstance(op[0].norm, self.norm_layer)
+            res[add_prefix(f'res_ops.{i}.0.norm', prefix)] = op[0].norm
+        return res
+
+    def get_named_first_dw_bn(self, prefix=None):
+        res = collections.OrderedDict()
+        for i, op in enumerate(self.dw_ops):
+            assert isinstance(op[0], ConvSyncBNReLU)
+            assert isinstance(op[0].norm, self.norm_layer)
+            res[add_prefix(f'dw_ops.{i}.0.norm', prefix)] = op[0].norm
+        return res
+
+    def get_named_first_bn(self, prefix=None):
+        return collections.OrderedDict(list(self.get_named_first_res_bn().items()) + list(self.get_named_first_dw_bn().items()))
+
+    def _shortcut(self, x):
+        if self.shortcut is None:
+            return x
+        return self.shortcut[1](self.shortcut[0](x))
+
+    def forward(self, x, seg):
+        branch_ops = list(self.res_ops) + list(self.dw_ops)
+        if not branch_ops:
+            return self._shortcut(x)
+        grad = x.requires_grad and torch.is_grad_enabled()
+        x_spade, x_short = ops.fanout(x, 2) if grad else (x, x)
+        tmp = self.spade(x_spade, seg, fuse_act=self.active)
+        tmp = self.active(tmp, applied=True)
+        return _run_branches(branch_ops, tmp, extra=(self._shortcut(x_short),))
+
+    def remove_spectral_norm(self):
+        raise NotImplementedError('remove_spectral_norm belongs to the export path (out of scope)')
+
+    def __repr__(self):
+        return ('{}({}, {}, res_channels={}, dw_channels={}, res_kernel_sizes={}, dw_kernel_sizes={})\n\tSPADE: {}').format(
+            self._get_name(), self.input_dim, self.input_dim, self.res_channels, self.dw_channels, self.res_kernel_sizes,
+            self.dw_kernel_sizes, self.spade)

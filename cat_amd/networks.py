@@ -78,6 +78,9 @@ def define_G(input_nc, output_nc, ngf, netG, norm='batch', dropout_rate=0, init_
                                  channels_reduction_factor=opt.channels_reduction_factor, kernel_sizes=opt.kernel_sizes,
                                  norm_layer=norm_layer, norm_momentum=opt.norm_momentum, norm_epsilon=opt.norm_epsilon,
                                  dropout_rate=dropout_rate, active_fn=opt.active_fn, n_blocks=9)
+    elif netG == 'inception_spade':
+        from .inception_spade_generator import InceptionSPADEGenerator
+        net = InceptionSPADEGenerator(opt)
     else:
         raise NotImplementedError('Generator model name [%s] is not recognized' % netG)
     return init_net(net, init_type, init_gain, gpu_ids)
@@ -86,7 +89,10 @@ def define_G(input_nc, output_nc, ngf, netG, norm='batch', dropout_rate=0, init_
 def define_D(input_nc, ndf, netD, n_layers_D=3, norm='batch', init_type='normal', init_gain=0.02, gpu_ids=[], opt=None):
     norm_layer = get_norm_layer(norm_type=norm, affine=getattr(opt, 'norm_affine_D', False),
                                 track_running_stats=getattr(opt, 'norm_track_running_stats', False))
-    if netD == 'n_layers':
+    if netD == 'multi_scale':
+        from .discriminators import MultiscaleDiscriminator
+        net = MultiscaleDiscriminator(opt)
+    elif netD == 'n_layers':
         from .discriminators import NLayerDiscriminator
         net = NLayerDiscriminator(input_nc, ndf, n_layers_D, norm_layer=norm_layer, active_fn=opt.active_fn_D)
     else:

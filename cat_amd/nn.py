@@ -140,6 +140,10 @@ class Conv2d(nn.Conv2d):
     unchanged (logical OIHW)."""
 
     def forward(self, x, fuse_act=None, fold_bn=None):
+        if 'weight_orig' in self._parameters:       # spectral_norm(conv): weight = weight_orig / sigma, computed per forward
+            if fold_bn is not None:
+                raise NotImplementedError('spectral norm + folded BatchNorm')
+            return self._conv(x, _sn_weight(self), self.bias, fuse_act)
         weight, bias = self.weight, self.bias
         if fold_bn is not None:
             weight, bias = _folded_eval_bn(self, fold_bn, 0)
@@ -218,14 +222,16 @@ class InstanceNorm2d(_NormMixin, nn.InstanceNorm2d):
         return self._run(x, L.NORM_INSTANCE, True, fuse_act)
 
 
-_FUSABLE = (Conv2d, ConvTranspose2d, BatchNorm2d, InstanceNorm2d)
+_FUSABLE = (Conv2d, ConvTranspose2d, BatchNorm2d, InstanceNorm2d)     # SynchronizedBatchNorm2d is a BatchNorm2d
 _NORMS = (BatchNorm2d, InstanceNorm2d)
 
 
 class FusedSequential(nn.Sequential):
     """nn.Sequential that hands the activation following a conv / norm to that layer's kernel epilogue."""
 
-    def forward(self, x):
+    def forward(self, x, fuse_act=None):
+        """`fuse_act`: an activation module that FOLLOWS this container (nested FusedSequential, e.g. the SPADE discriminator's
+        Sequential(Sequential(conv, norm), LeakyReLU)); it is handed to the last layer's epilogue."""
         mods = list(self)
         i, n = 0, len(mods)
         while i < n:
@@ -234,17 +240,96 @@ class FusedSequential(nn.Sequential):
             if isinstance(m, (Conv2d, ConvTranspose2d)) and _bn_folds(nxt):
                 # frozen network in eval mode: conv + BatchNorm(running stats) [+ activation] = ONE conv kernel
                 act = mods[i + 2] if i + 2 < n and isinstance(mods[i + 2], _ACTS) else None
+                if act is None and i + 2 == n:
+                    act, tail = fuse_act, True
+                else:
+                    tail = False
                 x = m(x, fuse_act=act, fold_bn=nxt)
                 x = nxt(x, applied=True)
                 i += 2
-                if act is not None:
+                if tail:
+                    fuse_act = None if act is not None else fuse_act
+                elif act is not None:
                     x = act(x, applied=True)
                     i += 1
-            elif isinstance(m, _FUSABLE) and isinstance(nxt, _ACTS):
+            elif isinstance(m, _FUSABLE + (FusedSequential,)) and isinstance(nxt, _ACTS):
                 x = m(x, fuse_act=nxt)
                 x = nxt(x, applied=True)
                 i += 2
+            elif i + 1 == n and fuse_act is not None and isinstance(m, _FUSABLE + (FusedSequential,)):
+                x = m(x, fuse_act=fuse_act)
+                fuse_act = None
+                i += 1
             else:
                 x = m(x)
                 i += 1
+        if fuse_act is not None:         # nothing could absorb it
+            x = fuse_act(x)
         return x
+
+# ---------------------------------------------------------------------------------------------- SPADE / GauGAN layers
+class SynchronizedBatchNorm2d(BatchNorm2d):
+    """models/modules/sync_batchnorm/batchnorm.py:SynchronizedBatchNorm2d.  Training mode: statistics over the samples of ALL
+    ranks (one RCCL all-reduce of [sum x | sum x^2] per layer, installed with ops.set_bn_sync); with one rank it is
+    F.batch_norm, exactly as the reference falls back (:69-72).  `num_batches_tracked` is never advanced (the reference's
+    forward bypasses _BatchNorm.forward)."""
+
+    def forward(self, x, fuse_act=None, applied=False):
+        if applied:
+            return x
+        if isinstance(x, Padded):
+            raise NotImplementedError('padding in front of a norm layer')
+        if self.training or not self.track_running_stats:
+            act, slope = _act_code(fuse_act)
+            track = self.training and self.track_running_stats
+            return ops.SyncBNFn.apply(x, self.weight, self.bias, self.running_mean if track else None,
+                                      self.running_var if track else None, float(self.eps), float(self.momentum), act, slope)
+        return self._run(x, L.NORM_BATCH, False, fuse_act)
+
+
+class Upsample(nn.Upsample):
+    """nn.Upsample(scale_factor=k), nearest (inception_spade_generator.py:45)."""
+
+    def forward(self, x):
+        if self.mode != 'nearest' or self.size is not None:
+            raise NotImplementedError('Upsample: nearest with an integer scale_factor only')
+        f = int(self.scale_factor)
+        if f != self.scale_factor:
+            raise NotImplementedError('Upsample: integer scale_factor only')
+        return ops.interp_nearest(x, (x.shape[2] * f, x.shape[3] * f))
+
+
+class MaxPool2d(nn.MaxPool2d):
+    def forward(self, x):
+        if self.kernel_size not in (2, (2, 2)) or self.stride not in (2, (2, 2)) or self.padding not in (0, (0, 0)):
+            raise NotImplementedError('MaxPool2d: only kernel 2, stride 2, padding 0 (VGG19)')
+        return ops.MaxPool2x2Fn.apply(x)
+
+
+def spectral_norm(module, name='weight', n_power_iterations=1, eps=1e-12):
+    """torch.nn.utils.spectral_norm for a cat_amd Conv2d: same parameter / buffer names (`weight_orig`, `weight_u`, `weight_v`), same
+    initialisation of u and v, one power iteration per training-mode forward.  As in torch, `module.weight` stays behind as a
+    plain tensor (which is what init_weights then re-initialises, not weight_orig)."""
+    if not isinstance(module, Conv2d) or module.groups != 1 or name != 'weight' or n_power_iterations != 1:
+        raise NotImplementedError('spectral_norm: dense cat_amd.nn.Conv2d weights, one power iteration')
+    weight = module._parameters.pop('weight')
+    o = weight.shape[0]
+    k = weight[0].numel()
+    with torch.no_grad():
+        u = torch.nn.functional.normalize(weight.new_empty(o).normal_(0, 1), dim=0, eps=eps)
+        v = torch.nn.functional.normalize(weight.new_empty(k).normal_(0, 1), dim=0, eps=eps)
+    module.register_parameter('weight_orig', weight)
+    setattr(module, 'weight', weight.data.clone())
+    module.register_buffer('weight_u', u)
+    module.register_buffer('weight_v', v)
+    module._cat_sn_eps = eps
+    return module
+
+
+def _sn_weight(module):
+    w = module.weight_orig
+    if w.is_cuda and ops.weight_wcs(w) != ops.cs_for(w.shape[1]):
+        new = ops.padded_weight_like(w.shape, w.device)
+        new.copy_(w.data)
+        w.data = new
+    return ops.SpectralNormFn.apply(w, module.weight_u, module.weight_v, module.training, module._cat_sn_eps)

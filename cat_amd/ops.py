@@ -637,3 +637,349 @@ def fill_(t, value):
     """In-place fill of a dense fp32 buffer with the library's kernel."""
     L.call('cat_fill', _p(t), t.numel(), float(value), _stream())
     return t
+
+
+# ---------------------------------------------------------------------------------------------- SPADE / GauGAN path
+_BN_SYNC = None
+
+
+def set_bn_sync(sync):
+    """`sync`: object with `.world_size` and `.all_reduce_sum_(tensor)` (cat_amd.parallel.DataParallelReducer) or None.  While set,
+    training-mode SynchronizedBatchNorm2d layers all-reduce their [sum x | sum x^2] (and backward sums) over the ranks."""
+    global _BN_SYNC
+    _BN_SYNC = sync if (sync is not None and sync.world_size > 1) else None
+
+
+def bn_sync():
+    return _BN_SYNC
+
+
+def _bn_forward_stats(x, rm, rv, eps, momentum, gamma, beta, want_affine):
+    """Split-phase batch statistics: local sums -> (all-reduce) -> mean / inv_std (+ running stats).  Returns
+    (a, b, scale, shift, count, sync): xhat = x*a + b;  y = x*scale + shift (affine map incl. gamma/beta) when want_affine."""
+    n, c, h, w = x.shape
+    cs = act_cs(x)
+    m = n * h * w
+    dev = x.device
+    st = _stream()
+    sync = _BN_SYNC
+    sums = torch.empty(2 * cs, device=dev, dtype=torch.float32)
+    ws = workspace(L.query('cat_bn_ws_bytes', m, cs), dev)
+    L.call('cat_bn_stats_fwd', _p(x), m, c, cs, _p(sums), _p(ws), st)
+    count = m
+    if sync is not None:
+        sync.all_reduce_sum_(sums)
+        count = m * sync.world_size
+    stats = torch.empty((4 + (2 if want_affine else 0), cs), device=dev, dtype=torch.float32)
+    mean, rstd, a, b = stats[0], stats[1], stats[2], stats[3]
+    scale, shift = (stats[4], stats[5]) if want_affine else (None, None)
+    L.call('cat_bn_finalize', _p(sums), float(count), c, cs, eps, 1 if sync is not None else 0, momentum, _p(gamma), _p(beta), _p(mean),
+           _p(rstd), _p(rm), _p(rv), _p(a), _p(b), _p(scale), _p(shift), st)
+    return a, b, scale, shift, count, sync
+
+
+class SyncBNFn(torch.autograd.Function):
+    """SynchronizedBatchNorm2d in training mode (+ fused activation): batch statistics over ALL ranks' samples
+    (models/modules/sync_batchnorm/batchnorm.py:68-140); with one rank it is F.batch_norm (:69-72)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, rm, rv, eps, momentum, act, slope):
+        _require_cuda(x)
+        x = conform(x)
+        n, c, h, w = x.shape
+        cs = act_cs(x)
+        a, b, scale, shift, count, sync = _bn_forward_stats(x, rm, rv, eps, momentum, gamma, beta, True)
+        y = empty_act(n, c, h, w, x.device, cs)
+        L.call('cat_affine_act_fwd', _p(x), _p(scale), _p(shift), _p(y), n * h * w, c, cs, act, slope, _stream())
+        ctx.meta = (count, sync, act, slope)
+        ctx.gamma, ctx.beta = gamma, beta
+        ctx.save_for_backward(x, a, b, gamma, beta)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, a, b, gamma, beta = ctx.saved_tensors
+        count, sync, act, slope = ctx.meta
+        n, c, h, w = x.shape
+        cs = act_cs(x)
+        m = n * h * w
+        dy = conform(dy)
+        if act_cs(dy) != cs:
+            raise RuntimeError('batch norm backward: gradient pixel stride differs from the input')
+        st = _stream()
+        sums = torch.empty(2 * cs, device=x.device, dtype=torch.float32)
+        ws = workspace(L.query('cat_bn_ws_bytes', m, cs), x.device)
+        L.call('cat_bn_stats_bwd', _p(x), _p(dy), _p(gamma), _p(beta), _p(a), _p(b), m, c, cs, act, slope, _p(sums), _p(ws), st)
+        local = sums
+        if sync is not None:
+            local = sums.clone()
+            sync.all_reduce_sum_(sums)
+        need_g = gamma is not None and ctx.needs_input_grad[1]
+        need_b = beta is not None and ctx.needs_input_grad[2]
+        dx = empty_act(n, c, h, w, x.device, cs) if ctx.needs_input_grad[0] else None
+        dgamma = dbeta = None
+        tg = _grad_target(ctx.gamma) if need_g else None
+        tb = _grad_target(ctx.beta) if need_b else None
+        if need_g and need_b and tg is not None and tb is not None:
+            sg, sb = ctx.gamma._cat_grad_state, ctx.beta._cat_grad_state
+            if sg['fresh'] != sb['fresh']:
+                raise RuntimeError('batch norm backward: gamma / beta gradient buffers out of sync')
+            acc = 0 if sg['fresh'] else 1
+            pg, pb = tg, tb
+            sg['fresh'] = sb['fresh'] = False
+        else:
+            acc = 0
+            pg = dgamma = torch.empty_like(gamma) if need_g else None
+            pb = dbeta = torch.empty_like(beta) if need_b else None
+        L.call('cat_bn_apply_bwd', _p(x), _p(dy), _p(gamma), _p(beta), _p(a), _p(b), _p(sums), float(count), _p(local), _p(dx), _p(pg), _p(pb),
+               acc, m, c, cs, act, slope, st)
+        return dx, dgamma, dbeta, None, None, None, None, None, None
+
+
+class SpadeFn(torch.autograd.Function):
+    """InceptionSPADE modulation in training mode, fused with the activation behind it:
+    y = act(param_free_norm(x) * (1 + gamma) + beta), gamma | beta = channel halves of `gb` (inception_modules.py:746-762)."""
+
+    @staticmethod
+    def forward(ctx, x, gb, rm, rv, eps, momentum, act, slope):
+        _require_cuda(x)
+        x, gb = conform(x), conform(gb)
+        n, c, h, w = x.shape
+        if gb.shape != (n, 2 * c, h, w):
+            raise RuntimeError(f'SPADE: modulation maps have shape {tuple(gb.shape)}, expected {(n, 2 * c, h, w)}')
+        cs, gcs = act_cs(x), act_cs(gb)
+        a, b, _, _, count, sync = _bn_forward_stats(x, rm, rv, eps, momentum, None, None, False)
+        y = empty_act(n, c, h, w, x.device, cs)
+        L.call('cat_spade_fwd', _p(x), _p(a), _p(b), _p(gb), _p(y), n * h * w, c, cs, gcs, act, slope, _stream())
+        ctx.meta = (count, sync, act, slope)
+        ctx.save_for_backward(x, a, b, gb, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, a, b, gb, y = ctx.saved_tensors
+        count, sync, act, slope = ctx.meta
+        n, c, h, w = x.shape
+        cs, gcs = act_cs(x), act_cs(gb)
+        m = n * h * w
+        dy = conform(dy)
+        if act_cs(dy) != cs:
+            raise RuntimeError('SPADE backward: gradient pixel stride differs from the input')
+        st = _stream()
+        dgb = empty_act(n, 2 * c, h, w, x.device, gcs)
+        dx = empty_act(n, c, h, w, x.device, cs)
+        sums = torch.empty(2 * cs, device=x.device, dtype=torch.float32)
+        ws = workspace(L.query('cat_bn_ws_bytes', m, cs), x.device)
+        L.call('cat_spade_bwd_stats', _p(x), _p(a), _p(b), _p(gb), _p(y), _p(dy), _p(dgb), _p(dx), _p(sums), m, c, cs, gcs, act, slope,
+               _p(ws), st)
+        if sync is not None:
+            sync.all_reduce_sum_(sums)
+        L.call('cat_spade_bwd_apply', _p(x), _p(a), _p(b), _p(sums), float(count), _p(dx), m, c, cs, st)
+        return (dx if ctx.needs_input_grad[0] else None), (dgb if ctx.needs_input_grad[1] else None), None, None, None, None, None, None
+
+
+def spade_eval(x, gb, rm, rv, eps, act, slope):
+    """Frozen (eval, no-grad) SPADE: the param-free norm uses the running statistics."""
+    _require_cuda(x)
+    x, gb = conform(x), conform(gb)
+    if torch.is_grad_enabled() and (x.requires_grad or gb.requires_grad):
+        raise NotImplementedError('eval-mode SPADE is only implemented for the frozen (no-grad) teacher')
+    n, c, h, w = x.shape
+    a, b = bn_fold(None, None, rm, rv, eps)
+    cs = act_cs(x)
+    if cs != c:     # bn_fold emits C entries; the kernels read cs (zero padded)
+        ap = torch.zeros(2, cs, device=x.device, dtype=torch.float32)
+        ap[0, :c].copy_(a)
+        ap[1, :c].copy_(b)
+        a, b = ap[0], ap[1]
+    y = empty_act(n, c, h, w, x.device, cs)
+    L.call('cat_spade_fwd', _p(x), _p(a), _p(b), _p(gb), _p(y), n * h * w, c, cs, act_cs(gb), act, slope, _stream())
+    return y
+
+
+class InterpNearestFn(torch.autograd.Function):
+    """F.interpolate(x, size, mode='nearest') / nn.Upsample(scale_factor=k).  Backward for integer up-scaling only."""
+
+    @staticmethod
+    def forward(ctx, x, ho, wo):
+        _require_cuda(x)
+        x = conform(x)
+        n, c, h, w = x.shape
+        y = empty_act(n, c, ho, wo, x.device)
+        L.call('cat_interp_nearest_fwd', _p(x), _p(y), n, h, w, ho, wo, c, act_cs(x), act_cs(y), _stream())
+        ctx.dims = (n, c, h, w, ho, wo)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        n, c, h, w, ho, wo = ctx.dims
+        f = ho // h
+        if ho != f * h or wo != f * w:
+            raise NotImplementedError('nearest interpolation backward: integer up-scaling only')
+        dy = conform(dy)
+        dx = empty_act(n, c, h, w, dy.device, act_cs(dy))
+        L.call('cat_upsample_nearest_bwd', _p(dy), _p(dx), n, h, w, f, c, act_cs(dy), _stream())
+        return dx, None, None
+
+
+def interp_nearest(x, size):
+    return InterpNearestFn.apply(x, int(size[0]), int(size[1]))
+
+
+class AvgPool3x3s2Fn(torch.autograd.Function):
+    """F.avg_pool2d(x, 3, stride=2, padding=1, count_include_pad=False) (discriminators.py:213-218)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _require_cuda(x)
+        x = conform(x)
+        n, c, h, w = x.shape
+        y = empty_act(n, c, (h - 1) // 2 + 1, (w - 1) // 2 + 1, x.device, act_cs(x))
+        L.call('cat_avgpool3x3s2_fwd', _p(x), _p(y), n, h, w, c, act_cs(x), _stream())
+        ctx.dims = (n, c, h, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        n, c, h, w = ctx.dims
+        dy = conform(dy)
+        dx = empty_act(n, c, h, w, dy.device, act_cs(dy))
+        L.call('cat_avgpool3x3s2_bwd', _p(dy), _p(dx), n, h, w, c, act_cs(dy), _stream())
+        return dx
+
+
+class MaxPool2x2Fn(torch.autograd.Function):
+    """nn.MaxPool2d(2, 2) (VGG19.features, models/modules/loss.py:151-186)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _require_cuda(x)
+        x = conform(x)
+        n, c, h, w = x.shape
+        y = empty_act(n, c, h // 2, w // 2, x.device, act_cs(x))
+        L.call('cat_maxpool2x2_fwd', _p(x), _p(y), n, h, w, c, act_cs(x), _stream())
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        n, c, h, w = x.shape
+        dy = conform(dy)
+        dx = empty_act(n, c, h, w, x.device, act_cs(x))
+        L.call('cat_maxpool2x2_bwd', _p(x), _p(dy), _p(dx), n, h, w, c, act_cs(x), _stream())
+        return dx
+
+
+def onehot_edges(label, inst, nc):
+    """SPADEModel.preprocess_input (models/spade_model.py:142-179): [N,1,H,W] integer label (+ instance ids) -> input_semantics."""
+    _require_cuda(label)
+    n, one, h, w = label.shape
+    lab = label.to(torch.int32).contiguous()
+    ins = None if inst is None else inst.to(torch.int32).contiguous()
+    c = nc + (0 if inst is None else 1)
+    y = empty_act(n, c, h, w, label.device)
+    L.call('cat_onehot_edges', _p(lab), _p(ins), _p(y), n, h, w, nc, act_cs(y), _stream())
+    return y
+
+
+class DiscInputFn(torch.autograd.Function):
+    """SPADEModelModules.discriminate's input (spade_model_modules.py:136-141): cat over the batch of [sem | fake] and
+    [sem | real].  Gradient flows to `fake` only."""
+
+    @staticmethod
+    def forward(ctx, sem, fake, real):
+        _require_cuda(sem)
+        sem, fake, real = conform(sem), conform(fake), conform(real)
+        n, cs_, h, w = sem.shape
+        ci = fake.shape[1]
+        y = empty_act(2 * n, cs_ + ci, h, w, sem.device)
+        ycs = act_cs(y)
+        half = n * h * w * ycs * 4
+        st = _stream()
+        L.call('cat_concat2', _p(sem), cs_, act_cs(sem), _p(fake), ci, act_cs(fake), _p(y), ycs, n * h * w, st)
+        L.call('cat_concat2', _p(sem), cs_, act_cs(sem), _p(real), ci, act_cs(real), C.c_void_p(y.data_ptr() + half), ycs, n * h * w, st)
+        ctx.dims = (n, cs_, ci, h, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        n, cs_, ci, h, w = ctx.dims
+        dy = conform(dy)
+        dfake = None
+        if ctx.needs_input_grad[1]:
+            dfake = empty_act(n, ci, h, w, dy.device)
+            L.call('cat_slice_channels', _p(dy), act_cs(dy), cs_, ci, _p(dfake), act_cs(dfake), n * h * w, _stream())
+        return None, dfake, None
+
+
+class BatchHalvesFn(torch.autograd.Function):
+    """divide_pred (spade_model_modules.py:143-155): the fake / real halves of a tensor computed on the 2N batch."""
+
+    @staticmethod
+    def forward(ctx, t):
+        t = conform(t)
+        n2 = t.shape[0]
+        ctx.shape = tuple(t.shape)
+        ctx.cs = act_cs(t)
+        return t[:n2 // 2], t[n2 // 2:]
+
+    @staticmethod
+    def backward(ctx, d0, d1):
+        n2, c, h, w = ctx.shape
+        dev = (d0 if d0 is not None else d1).device
+        dy = empty_act(n2, c, h, w, dev, ctx.cs)
+        half = (n2 // 2) * h * w * ctx.cs
+        st = _stream()
+        for k, d in enumerate((d0, d1)):
+            dst = C.c_void_p(dy.data_ptr() + k * half * 4)
+            if d is None:
+                L.call('cat_fill', dst, half, 0.0, st)
+            else:
+                d = conform(d)
+                arr = (C.c_void_p * 1)(d.data_ptr())
+                L.call('cat_add_n', arr, 1, dst, half, st)
+        return dy
+
+
+class SpectralNormFn(torch.autograd.Function):
+    """torch.nn.utils.spectral_norm's pre-forward hook (spade_architecture/normalization.py:27-29): one power iteration on the
+    persistent u / v (training mode, in place, no grad), weight = weight_orig / sigma."""
+
+    @staticmethod
+    def forward(ctx, weight_orig, u, v, power_iter, eps):
+        _require_cuda(weight_orig)
+        wcl, wcs = weight_cl(weight_orig)
+        o, i, kh, kw = weight_orig.shape
+        taps = kh * kw
+        dev = weight_orig.device
+        w_sn = padded_weight_like(weight_orig.shape, dev)
+        if weight_wcs(w_sn) != wcs:
+            raise RuntimeError('spectral norm: weight layout mismatch')
+        vp = torch.empty(taps * wcs, device=dev, dtype=torch.float32)
+        sigma = torch.empty(1, device=dev, dtype=torch.float32)
+        ws = workspace(L.query('cat_spectral_norm_ws_bytes', o, i, taps, wcs), dev)
+        L.call('cat_spectral_norm_fwd', _p(wcl), o, i, taps, wcs, _p(u), _p(v), 1 if power_iter else 0, eps, _p(sigma), _p(w_sn), _p(vp),
+               _p(ws), _stream())
+        ctx.geom = (o, taps, wcs)
+        ctx.weight = weight_orig
+        ctx.save_for_backward(w_sn, u.clone() if power_iter else u, vp, sigma)
+        return w_sn
+
+    @staticmethod
+    def backward(ctx, gw):
+        w_sn, u, vp, sigma = ctx.saved_tensors
+        o, taps, wcs = ctx.geom
+        if weight_wcs(gw) != wcs:
+            g2 = padded_weight_like(w_sn.shape, gw.device)
+            g2.copy_(gw)
+            gw = g2
+        ws = workspace(L.query('cat_spectral_norm_ws_bytes', o, 0, taps, wcs), gw.device)
+        st = _stream()
+
+        def k(dst, acc):
+            if _grad_wcs(dst) != wcs:
+                raise RuntimeError('spectral norm backward: gradient buffer layout mismatch')
+            L.call('cat_spectral_norm_bwd', _p(gw), _p(w_sn), _p(u), _p(vp), _p(sigma), o, taps, wcs, _p(dst), acc, _p(ws), st)
+        dw = _write_param_grad(ctx.weight, k)
+        return dw, None, None, None, None

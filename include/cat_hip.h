@@ -156,6 +156,70 @@ double cat_prof_family_bytes(int i);
 int cat_fill(float* p, int64_t n, float v, cat_stream_t stream);
 int cat_axpy(float* y, const float* x, int64_t n, float a, cat_stream_t stream); /* y += a*x */
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * GauGAN / SPADE distillation step (distillers/base_spade_distiller.py:226-234).
+ *
+ * Split-phase batch normalisation: replaces _SynchronizedBatchNorm.forward / _data_parallel_master / _compute_mean_std
+ * (models/modules/sync_batchnorm/batchnorm.py:68-140) and F.batch_norm on one device (:69-72).  The host all-reduces
+ * `sums` (2*cs floats: [sum x | sum x^2], or [sum g | sum g*xhat] in the backward) over RCCL between the calls; on one
+ * GPU the calls simply follow each other.  a[c] = inv_std, b[c] = -mean*inv_std (xhat = x*a + b), zero on padding.
+ * clamp = 1: inv_std = max(var, eps)^-1/2 (batchnorm.py:140, >1 replica); clamp = 0: (var+eps)^-1/2 (F.batch_norm). */
+size_t cat_bn_ws_bytes(int64_t M, int cs);
+int cat_bn_stats_fwd(const float* x, int64_t M, int C, int cs, float* sums, void* ws, cat_stream_t stream);
+int cat_bn_finalize(const float* sums, double count, int C, int cs, float eps, int clamp, float momentum,
+                    const float* gamma, const float* beta, float* mean, float* rstd, float* running_mean,
+                    float* running_var, float* a, float* b, float* scale, float* shift, cat_stream_t stream);
+/* y = act(x*scale + shift) is cat_affine_act_fwd.  Backward: g = dy * act'(gamma*xhat + beta). */
+int cat_bn_stats_bwd(const float* x, const float* dy, const float* gamma, const float* beta, const float* a,
+                     const float* b, int64_t M, int C, int cs, int act, float slope, float* sums, void* ws,
+                     cat_stream_t stream);
+/* dx = gamma*inv_std*(g - sums[0]/count - xhat*sums[1]/count); dgamma (+)= local_sums[1], dbeta (+)= local_sums[0]. */
+int cat_bn_apply_bwd(const float* x, const float* dy, const float* gamma, const float* beta, const float* a,
+                     const float* b, const float* sums, double count, const float* local_sums, float* dx,
+                     float* dgamma, float* dbeta, int accumulate, int64_t M, int C, int cs, int act, float slope,
+                     cat_stream_t stream);
+
+/* InceptionSPADE.forward (models/modules/inception_modules.py:746-762) fused with the activation that
+ * SPADEInvertedResidualChannels.forward applies to it (:553):  y = act((x*a + b) * (1 + gamma) + beta), where
+ * gb: [M][gcs] holds gamma in channels [0,C) and beta in [C,2C) (the summed branch outputs, :756-759).
+ * Backward pass 1 writes dgb (d gamma | d beta), dxh = g*(1+gamma) and sums = [sum dxh | sum dxh*xhat];
+ * pass 2 (after the all-reduce of sums) turns dxh into dx in place (param_free_norm backward). */
+int cat_spade_fwd(const float* x, const float* a, const float* b, const float* gb, float* y, int64_t M, int C,
+                  int cs, int gcs, int act, float slope, cat_stream_t stream);
+int cat_spade_bwd_stats(const float* x, const float* a, const float* b, const float* gb, const float* y,
+                        const float* dy, float* dgb, float* dxh, float* sums, int64_t M, int C, int cs, int gcs,
+                        int act, float slope, void* ws, cat_stream_t stream);
+int cat_spade_bwd_apply(const float* x, const float* a, const float* b, const float* sums, double count, float* dx,
+                        int64_t M, int C, int cs, cat_stream_t stream);
+
+/* F.interpolate(mode='nearest') of the segmentation map (inception_modules.py:748, inception_spade_generator.py:67)
+ * and nn.Upsample(scale_factor=2) (:45): src = min(floor(dst * in/out), in-1).  Backward for integer factor f. */
+int cat_interp_nearest_fwd(const float* x, float* y, int N, int Hi, int Wi, int Ho, int Wo, int C, int xcs, int ycs,
+                           cat_stream_t stream);
+int cat_upsample_nearest_bwd(const float* dy, float* dx, int N, int Hi, int Wi, int f, int C, int cs,
+                             cat_stream_t stream);
+/* MultiscaleDiscriminator.downsample: F.avg_pool2d(3, stride 2, padding 1, count_include_pad=False)
+ * (models/modules/discriminators.py:213-218).  Ho = (H-1)/2+1. */
+int cat_avgpool3x3s2_fwd(const float* x, float* y, int N, int H, int W, int C, int cs, cat_stream_t stream);
+int cat_avgpool3x3s2_bwd(const float* dy, float* dx, int N, int H, int W, int C, int cs, cat_stream_t stream);
+/* nn.MaxPool2d(2,2) inside VGG19.features (models/modules/loss.py:151-186). */
+int cat_maxpool2x2_fwd(const float* x, float* y, int N, int H, int W, int C, int cs, cat_stream_t stream);
+int cat_maxpool2x2_bwd(const float* x, const float* dy, float* dx, int N, int H, int W, int C, int cs,
+                       cat_stream_t stream);
+/* SPADEModel.preprocess_input + get_edges (models/spade_model.py:142-179): label -> one-hot over nc channels,
+ * instance ids -> 4-neighbour edge map in channel nc (inst may be NULL = --no_instance).  y: [N][H][W][cs]. */
+int cat_onehot_edges(const int* label, const int* inst, float* y, int N, int H, int W, int nc, int cs,
+                     cat_stream_t stream);
+/* torch.nn.utils.spectral_norm on the discriminator convs (spade_architecture/normalization.py:17-50): one power
+ * iteration (power_iter=1, training) updating u [O] and v [I*taps, torch (i,kh,kw) order] in place, sigma = u.W v,
+ * w_sn = w / sigma.  w, w_sn: [O][taps][wcs]; vp: [taps][wcs] scratch kept for the backward.
+ * Backward: d weight_orig (+)= (gw - <gw, w_sn> u v^T) / sigma. */
+size_t cat_spectral_norm_ws_bytes(int O, int I, int taps, int wcs);
+int cat_spectral_norm_fwd(const float* w, int O, int I, int taps, int wcs, float* u, float* v, int power_iter,
+                          float eps, float* sigma, float* w_sn, float* vp, void* ws, cat_stream_t stream);
+int cat_spectral_norm_bwd(const float* gw, const float* w_sn, const float* u, const float* vp, const float* sigma,
+                          int O, int taps, int wcs, float* dw, int accumulate, void* ws, cat_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
