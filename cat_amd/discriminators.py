@@ -69,10 +69,17 @@ class SPADENLayerDiscriminator(BaseNetwork):
         return opt.semantic_nc + opt.output_nc
 
     def forward(self, input):
-        results = [input]
-        for submodel in self.children():
-            results.append(submodel(results[-1]))
-        return results[1:]
+        results = []
+        x = input
+        subs = list(self.children())
+        for i, submodel in enumerate(subs):
+            y = submodel(x)
+            if i + 1 < len(subs) and torch.is_grad_enabled() and y.requires_grad:
+                tap, x = ops.fanout(y, 2)      # returned to the caller (feature matching) AND fed to the next layer
+            else:
+                tap = x = y
+            results.append(tap)
+        return results
 
 
 class MultiscaleDiscriminator(nn.Module):

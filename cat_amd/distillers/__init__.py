@@ -9,7 +9,7 @@ def find_distiller_using_name(distiller_name):
     try:
         modellib = importlib.import_module(distiller_filename)
     except ModuleNotFoundError as e:
-        raise NotImplementedError('distiller [%s] is not part of the accelerated hot path (inception only this round)'
+        raise NotImplementedError('distiller [%s] is not part of the accelerated hot path (inception and spade are)'
                                   % distiller_name) from e
     target = distiller_name.replace('_', '') + 'distiller'
     for name, cls in modellib.__dict__.items():

@@ -1,6 +1,7 @@
 """InceptionSPADEGenerator (GauGAN student / teacher): same constructor, attribute names, state_dict keys and forward contract
 (`mapping_layers` -> (image, {name: activation})) as the reference's
 models/modules/inception_architecture/inception_spade_generator.py:14-143, every op a gfx950 kernel."""
+import torch
 from torch import nn
 
 from . import nn as cnn
@@ -55,29 +56,29 @@ class InceptionSPADEGenerator(BaseNetwork):
         ret_acts = {}
 
         def keep(name, t):
-            if name in mapping_layers:
+            """Tap `t` for the distillation loss; returns the tensor the network continues with (two consumers -> FanoutFn)."""
+            if name not in mapping_layers:
+                return t
+            if torch.is_grad_enabled() and t.requires_grad:
+                ret_acts[name], t = ops.fanout(t, 2)
+            else:
                 ret_acts[name] = t
+            return t
 
         x = seg_at(seg, (self.sh, self.sw))
-        x = self.fc_norm(self.fc(x))
-        keep('fc', x)
-        x = self.head_0(x, seg)
-        keep('head_0', x)
+        x = keep('fc', self.fc_norm(self.fc(x)))
+        x = keep('head_0', self.head_0(x, seg))
         x = self.up(x)
-        x = self.G_middle_0(x, seg)
-        keep('G_middle_0', x)
+        x = keep('G_middle_0', self.G_middle_0(x, seg))
         if self.opt.num_upsampling_layers in ('more', 'most'):
             x = self.up(x)
-        x = self.G_middle_1(x, seg)
-        keep('G_middle_1', x)
+        x = keep('G_middle_1', self.G_middle_1(x, seg))
         for name in ('up_0', 'up_1', 'up_2', 'up_3'):
             x = self.up(x)
-            x = getattr(self, name)(x, seg)
-            keep(name, x)
+            x = keep(name, getattr(self, name)(x, seg))
         if self.opt.num_upsampling_layers == 'most':
             x = self.up(x)
-            x = self.up_4(x, seg)
-            keep('up_4', x)
+            x = keep('up_4', self.up_4(x, seg))
         x = self.conv_img(self._lrelu(x), fuse_act=self._tanh)      # F.leaky_relu(x, 2e-1) -> conv_img -> tanh (:117-118)
         if len(mapping_layers) == 0:
             return x

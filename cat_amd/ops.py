@@ -14,6 +14,7 @@ from . import _lib as L
 from ._lib import ConvGeom, NormGeom
 
 STATS = {'conform_copies': 0}   # non-native layout fix-ups; must stay 0 on the distillation hot path
+_STRICT_LAYOUT = os.environ.get('CAT_STRICT_LAYOUT', '0') == '1'     # debugging aid: raise where a fix-up would happen
 
 
 # ---------------------------------------------------------------------------------------------- layout helpers
@@ -141,6 +142,8 @@ def conform(t):
     if is_act(t):
         return t
     STATS['conform_copies'] += 1
+    if _STRICT_LAYOUT:
+        raise RuntimeError(f'non-native activation layout: shape {tuple(t.shape)}, strides {t.stride()}, dtype {t.dtype}')
     if t.is_contiguous():
         return to_nhwc(t)
     n, c, h, w = t.shape
@@ -510,6 +513,7 @@ class FanoutFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, k):
         ctx.k = k
+        ctx.set_materialize_grads(False)      # an unused alias contributes None, not a torch-allocated zero tensor
         return tuple(x.view_as(x) for _ in range(k))
 
     @staticmethod
@@ -922,10 +926,13 @@ class BatchHalvesFn(torch.autograd.Function):
         n2 = t.shape[0]
         ctx.shape = tuple(t.shape)
         ctx.cs = act_cs(t)
+        ctx.set_materialize_grads(False)
         return t[:n2 // 2], t[n2 // 2:]
 
     @staticmethod
     def backward(ctx, d0, d1):
+        if d0 is None and d1 is None:
+            return None
         n2, c, h, w = ctx.shape
         dev = (d0 if d0 is not None else d1).device
         dy = empty_act(n2, c, h, w, dev, ctx.cs)

@@ -84,10 +84,23 @@ class DataParallelReducer:
         self.reduce_async(optimizer_or_tensors).wait()
 
     def broadcast_parameters(self, modules, src=0):
-        """Replicas start identical (DataParallel replicates GPU 0's module every forward)."""
+        """Replicas start identical (DataParallel replicates GPU 0's module every forward).  Conv weights may already live in
+        their padded channels_last storage (a strided view): those travel through a dense staging copy."""
         for m in modules:
             for t in list(m.parameters()) + list(m.buffers()):
-                dist.broadcast(t.data, src=src, group=self.group)
+                d = t.data
+                if d.is_contiguous():
+                    dist.broadcast(d, src=src, group=self.group)
+                else:
+                    stage = d.contiguous()
+                    dist.broadcast(stage, src=src, group=self.group)
+                    d.copy_(stage)
+
+    def all_reduce_sum_(self, t):
+        """In-place sum over ranks, ordered with the CURRENT stream (SynchronizedBatchNorm's [sum x | sum x^2] exchange,
+        models/modules/sync_batchnorm/batchnorm.py:103-123: ReduceAddCoalesced + Broadcast become one all-reduce)."""
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
 
     def max_over_ranks(self, seconds):
         t = torch.tensor([seconds], dtype=torch.float64, device='cuda' if dist.get_backend(self.group) == 'nccl' else 'cpu')

@@ -15,14 +15,22 @@ import torch
 from torch import nn
 
 from . import nn as cnn
-from .inception_modules import InvertedResidualChannels
+from .inception_modules import (Conv, ConvSyncBNReLU, InceptionSPADE, InvertedResidualChannels, SPADEInvertedResidualChannels)
 from .optim import FusedAdam
 
 
-def get_bn_to_prune(model, verbose=False):
+def get_bn_to_prune(model, verbose=False, spade=False):
+    """utils/prune.py:5-61: ordered names of the first-BN scales of every block (SPADE: the block's own branches, then the
+    branches of its InceptionSPADE)."""
     weights = []
     for name, m in model.get_named_block_list().items():
-        if isinstance(m, InvertedResidualChannels):
+        if spade:
+            if isinstance(m, SPADEInvertedResidualChannels):
+                weights += ['{}.weight'.format(n) for n in m.get_named_first_res_bn(prefix=name)]
+                weights += ['{}.weight'.format(n) for n in m.get_named_first_dw_bn(prefix=name)]
+                weights += ['{}.weight'.format(n) for n in m.spade.get_named_first_res_bn(prefix=name + '.spade')]
+                weights += ['{}.weight'.format(n) for n in m.spade.get_named_first_dw_bn(prefix=name + '.spade')]
+        elif isinstance(m, InvertedResidualChannels):
             weights += ['{}.weight'.format(n) for n in m.get_named_first_res_bn(prefix=name)]
             weights += ['{}.weight'.format(n) for n in m.get_named_first_dw_bn(prefix=name)]
     if verbose:
@@ -73,13 +81,78 @@ def _profile(m, shape):
             shape = _profile(sub, shape)
             m.n_macs += getattr(sub, 'n_macs', 0)
         return shape
+    if isinstance(m, ConvSyncBNReLU):          # model_profiling.py:179-185
+        shape = _profile(m.conv, shape)
+        shape = _profile(m.norm, shape)
+        m.n_macs = m.conv.n_macs + m.norm.n_macs
+        return shape
+    if isinstance(m, Conv):                    # :186-191
+        shape = _profile(m.conv, shape)
+        m.n_macs = m.conv.n_macs
+        return shape
+    if isinstance(m, InceptionSPADE):          # :192-201; the branches run on the (resized) segmentation map
+        seg_shape = (n, m.input_dim, h, w)
+        _profile(m.param_free_norm, shape)
+        m.n_macs = m.param_free_norm.n_macs
+        for op in list(m.res_ops) + list(m.dw_ops):
+            _profile(op, seg_shape)
+            m.n_macs += op.n_macs
+        return shape
+    if isinstance(m, SPADEInvertedResidualChannels):   # :166-178
+        m.n_macs = 0
+        out_shape = (n, m.output_dim, h, w)
+        if len(m.res_ops) + len(m.dw_ops) == 0:       # forward returns before the SPADE / branch hooks can fire
+            if m.shortcut is not None:
+                _profile(m.shortcut, shape)
+                m.n_macs += m.shortcut.n_macs
+            return out_shape
+        _profile(m.spade, shape)
+        for op in list(m.res_ops) + list(m.dw_ops):
+            _profile(op, shape)
+            m.n_macs += op.n_macs
+        if m.shortcut is not None:
+            _profile(m.shortcut, shape)
+            m.n_macs += m.shortcut.n_macs
+        m.n_macs += m.spade.n_macs
+        return out_shape
     m.n_macs = 0
     return shape
 
 
+def _profile_spade_generator(model, shape):
+    """InceptionSPADEGenerator.forward (inception_spade_generator.py:63-124) as shape propagation: n_macs = sum over the direct
+    children (model_profiling.py:203-213); nn.Upsample and activations count zero."""
+    n, c, h, w = shape
+    cur = _profile(model.fc, (n, c, model.sh, model.sw))
+    cur = _profile(model.fc_norm, cur)
+    total = model.fc.n_macs + model.fc_norm.n_macs
+
+    def up(sh):
+        return (sh[0], sh[1], sh[2] * 2, sh[3] * 2)
+
+    nul = model.opt.num_upsampling_layers
+    cur = _profile(model.head_0, cur)
+    cur = _profile(model.G_middle_0, up(cur))
+    cur = _profile(model.G_middle_1, up(cur) if nul in ('more', 'most') else cur)
+    total += model.head_0.n_macs + model.G_middle_0.n_macs + model.G_middle_1.n_macs
+    for name in ('up_0', 'up_1', 'up_2', 'up_3') + (('up_4',) if nul == 'most' else ()):
+        blk = getattr(model, name)
+        cur = _profile(blk, up(cur))
+        total += blk.n_macs
+    cur = _profile(model.conv_img, cur)
+    total += model.conv_img.n_macs
+    model.up.n_macs = 0
+    return total
+
+
 def model_profiling(model, height, width, batch=1, channel=3, **unused):
-    """n_macs of an InceptionGenerator (and of .down_sampling / .features / .up_sampling) at batch x channel x H x W."""
+    """n_macs of an InceptionGenerator (and of .down_sampling / .features / .up_sampling) or of an InceptionSPADEGenerator at
+    batch x channel x H x W."""
     shape = (batch, channel, height, width)
+    if hasattr(model, 'head_0'):          # InceptionSPADEGenerator
+        model.n_macs = _profile_spade_generator(model, shape)
+        model.n_params = sum(p.numel() for p in model.parameters())
+        return model.n_macs, model.n_params
     total = 0
     for part in (model.down_sampling, model.features, model.up_sampling):
         shape = _profile(part, shape)
@@ -303,8 +376,96 @@ def shrink_model(model, target_flops, opt, verbose=True):
     return thr, searched
 
 
+def spade_search(teacher, target_flops, opt):
+    """The threshold search of shrink_spade_model (utils/common.py:710-812): binary search on |gamma| of fc_norm + every first BN of
+    the blocks and of their SPADE layers; the trunk width is count(|fc_norm.gamma| > thr) rounded DOWN to a multiple of 16 (32 for
+    'most') with the prune_cin_lb / prune_cin_ub floors applied in units of that multiple.  Returns
+    (threshold, searched n_macs, student network with the searched ARCHITECTURE and freshly initialised weights)."""
+    netG_tmp = copy.deepcopy(teacher).cpu()
+    named = dict(netG_tmp.named_parameters())
+    weights = [netG_tmp.fc_norm.weight] + [named[n] for n in get_bn_to_prune(netG_tmp, spade=True)]
+    allw = torch.cat([w.detach().abs().float() for w in weights])
+    lb, ub = allw.min(), allw.max()
+    searched, thr, cand = float('inf'), None, None
+    nul = opt.num_upsampling_layers
+    ch_div = 32 if nul == 'most' else 16
+    features = ['head_0', 'G_middle_0', 'G_middle_1'] + ['up_%d' % i for i in range(5 if nul == 'most' else 4)]
+    norm_layer = type(netG_tmp.fc_norm)
+    while (abs(ub - lb) > 1e-3 * lb) or (searched > target_flops):
+        cand = copy.deepcopy(netG_tmp)
+        thr = (lb + ub) / 2
+        out_channels = (cand.fc_norm.weight.detach().abs() > thr).sum().item()
+        out_channels = max(out_channels // ch_div, getattr(opt, 'prune_cin_lb', 1)) * ch_div
+        out_channels = min(out_channels // ch_div, getattr(opt, 'prune_cin_ub', float('inf'))) * ch_div
+        ngf_stu = out_channels // 16
+        cand.fc_norm = norm_layer(out_channels, affine=True)
+        old = cand.fc
+        cand.fc = cnn.Conv2d(old.in_channels, out_channels, kernel_size=old.kernel_size, stride=old.stride, padding=old.padding,
+                             bias=old.bias is not None)
+        in_channels = out_channels
+        for layer_name in features:
+            layer = getattr(cand, layer_name)
+            layer.input_dim = in_channels
+            out_channels = in_channels // 2 if 'up' in layer_name else in_channels
+            layer.output_dim = out_channels
+            layer.res_channels = [int((bn.weight.detach().abs() > thr).sum().item()) for bn in layer.get_first_res_bn()]
+            layer.dw_channels = [int((bn.weight.detach().abs() > thr).sum().item()) for bn in layer.get_first_dw_bn()]
+            layer.spade.output_dim = layer.input_dim
+            layer.spade.res_channels = [int((bn.weight.detach().abs() > thr).sum().item()) for bn in layer.spade.get_first_res_bn()]
+            layer.spade.dw_channels = [int((bn.weight.detach().abs() > thr).sum().item()) for bn in layer.spade.get_first_dw_bn()]
+            layer.res_ops, layer.dw_ops, layer.shortcut, layer.spade = layer._build(build_only=True)
+            in_channels = out_channels
+        old = cand.conv_img
+        cand.conv_img = cnn.Conv2d(in_channels, old.out_channels, kernel_size=old.kernel_size, stride=old.stride, padding=old.padding,
+                                   bias=old.bias is not None)
+        searched, _ = model_profiling(cand, opt.data_height, opt.data_width, channel=opt.data_channel)
+        if searched > target_flops:
+            lb = thr
+        else:
+            ub = thr
+    return thr, searched, cand, ngf_stu
+
+
+def shrink_spade_model(model, target_flops, opt, verbose=True):
+    """utils/common.py:710-869: the student becomes the searched architecture (no weight copy: its tensors keep torch's default
+    initialisation, as in the reference), netAs / optimizer_G / schedulers are rebuilt."""
+    from . import networks
+    m = model.modules_on_one_gpu
+    thr, searched, student, ngf_stu = spade_search(m.netG_teacher, target_flops, opt)
+    if verbose:
+        print(f'scale threshold: {thr}, searched flops: {searched}, target flops: {target_flops}, '
+              f'flops diff: {searched - target_flops}.')
+    m.netG_student = student.to(model.device)
+    model.shrink_threshold = thr
+    model_profiling(m.netG_student, opt.data_height, opt.data_width, channel=opt.data_channel)
+    netAs = nn.ModuleList()
+    for mapping_layer in m.mapping_layers:
+        if mapping_layer != 'up_1':
+            fs, ft = ngf_stu * 16, opt.teacher_ngf * 16
+        else:
+            fs, ft = ngf_stu * 4, opt.teacher_ngf * 4
+        netAs.append(cnn.Conv2d(in_channels=fs, out_channels=ft, kernel_size=1))
+    m.netAs = netAs.to(model.device)
+    if opt.no_TTUR:
+        beta1, beta2, g_lr = opt.beta1, opt.beta2, opt.lr
+    else:
+        beta1, beta2, g_lr = 0.0, 0.9, opt.lr / 2
+    g_params = list(m.netG_student.parameters())
+    for netA in m.netAs:
+        g_params += list(netA.parameters())
+    model.optimizer_G = FusedAdam(g_params, lr=g_lr, betas=(beta1, beta2))
+    model.optimizers = [model.optimizer_G, model.optimizer_D]
+    if model.isTrain:
+        model.schedulers = [networks.get_scheduler(o, opt) for o in model.optimizers]
+    if verbose:
+        print('All layers are pruned.')
+    return thr, searched
+
+
 def shrink(model, opt):
-    """reference utils/common.py:872-878 dispatch (inception distillers only in this build)."""
+    """reference utils/common.py:872-878."""
+    target_flops = getattr(opt, 'target_flops', 0.0)
+    assert target_flops > 0
     if 'spade' in getattr(opt, 'distiller', 'inception'):
-        raise NotImplementedError('SPADE shrink is outside this round (SURVEY §8f rank 2)')
-    return shrink_model(model, opt.target_flops, opt)
+        return shrink_spade_model(model, target_flops, opt)
+    return shrink_model(model, target_flops, opt)

@@ -54,7 +54,20 @@ def test_factory_and_flags():
     assert o.teacher_ngf == 64 and o.student_ngf == 48 and o.lambda_recon == 100 and o.distill_G_loss_type == 'mse'
     assert o.norm == 'instance' and o.dataset_mode == 'aligned' and o.pretrained_ngf == 64 and o.target_flops == 0
     with pytest.raises(NotImplementedError):
-        find_distiller_using_name('spade')
+        find_distiller_using_name('munit')
+    # --distiller spade: flags and defaults of base_spade_distiller.py:27-138 / spade_distiller.py:24-84 / discriminators.py:185-203
+    assert find_distiller_using_name('spade').__name__ == 'SPADEDistiller'
+    p = argparse.ArgumentParser()
+    for flag, d in (('--netD', 'n_layers'), ('--ndf', 128), ('--dataset_mode', None), ('--batch_size', 1), ('--print_freq', 100),
+                    ('--save_latest_freq', 1), ('--save_epoch_freq', 1), ('--nepochs', 1), ('--nepochs_decay', 1), ('--init_type', 'normal'),
+                    ('--n_layers_D', 3)):
+        p.add_argument(flag, default=d)
+    get_option_setter('spade')(p, True)
+    o = p.parse_args([])
+    assert o.teacher_ngf == 64 and o.student_ngf == 48 and o.teacher_norm_G == 'spadesyncbatch3x3' and o.num_upsampling_layers == 'more'
+    assert o.lambda_feat == 10 and o.lambda_vgg == 10 and o.lambda_distill == 10 and o.netD == 'multi_scale' and o.ndf == 64
+    assert o.num_D == 2 and o.norm_D == 'spectralinstance' and o.n_layers_D == 4 and o.init_type == 'xavier' and o.prune_cin_lb == 1
+    assert o.no_TTUR is False and o.batch_size == 16
 
 
 def test_no_cpu_fallback():

@@ -104,3 +104,78 @@ def test_data_parallel_semantics_world2_gloo():
         assert p.exitcode == 0
     err = q.get(timeout=10)
     assert err < 1e-4, err
+
+
+def _worker_syncbn(rank, world, port, q):
+    """The SynchronizedBatchNorm exchange protocol of cat_amd.ops.SyncBNFn (sums layout, count, clamp, local parameter gradients
+    + bucket averaging), restated with torch ops on CPU over gloo, against the oracle's whole-batch sync_bn."""
+    from cat_amd import parallel
+    from oracle import detfill
+    from oracle import ref_spade_cpu as R
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    parallel.init_distributed(backend='gloo')
+    red = parallel.DataParallelReducer()
+    c, eps = 5, 1e-5
+    X = detfill.normal((4, c, 6, 7), 300) * 2 + 1
+    X[:, 0] = 0.75                                   # zero-variance channel -> clamp(eps) path
+    DY = detfill.normal((4, c, 6, 7), 301)
+    gamma, beta = 1 + 0.2 * detfill.normal((c,), 302), 0.1 * detfill.normal((c,), 303)
+    x, dy = X.chunk(world, 0)[rank], DY.chunk(world, 0)[rank]
+    m = x.shape[0] * x.shape[2] * x.shape[3]
+    sums = torch.cat([x.sum((0, 2, 3)), (x * x).sum((0, 2, 3))])          # [sum x | sum x^2]  (cat_bn_stats_fwd)
+    red.all_reduce_sum_(sums)
+    count = m * world
+    mean = sums[:c] / count
+    var = ((sums[c:] - sums[:c] * mean) / count).clamp_min(0)
+    a = var.clamp(eps) ** -0.5                                             # cat_bn_finalize, clamp = 1
+    b = -mean * a
+    xh = x * a.view(1, -1, 1, 1) + b.view(1, -1, 1, 1)
+    pre = xh * gamma.view(1, -1, 1, 1) + beta.view(1, -1, 1, 1)
+    g = dy * (pre > 0).float()                                             # fused ReLU
+    local = torch.cat([g.sum((0, 2, 3)), (g * xh).sum((0, 2, 3))])         # cat_bn_stats_bwd
+    tot = red.all_reduce_sum_(local.clone())
+    dx = (gamma * a).view(1, -1, 1, 1) * (g - (tot[:c] / count).view(1, -1, 1, 1) - xh * (tot[c:] / count).view(1, -1, 1, 1))
+    dgamma, dbeta = local[c:].clone(), local[:c].clone()                   # LOCAL sums; the gradient bucket is then averaged
+    bucket = torch.cat([dgamma, dbeta])
+    red.reduce([bucket])
+    bucket = bucket / world
+    # non-contiguous parameter broadcast (padded channels_last conv weight)
+    w = torch.zeros(3, 2, 2, 4)[..., :3].permute(0, 3, 1, 2)
+    w.copy_(detfill.normal((3, 3, 2, 2), 310 + rank))
+
+    class M(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(w)
+    mod = M()
+    red.broadcast_parameters([mod])
+    assert torch.equal(mod.w.detach(), detfill.normal((3, 3, 2, 2), 310)) and not mod.w.is_contiguous()
+    # oracle: whole batch, loss = mean over replicas of the per-replica loss
+    sd = {'n.weight': gamma.clone().requires_grad_(True), 'n.bias': beta.clone().requires_grad_(True),
+          'n.running_mean': torch.zeros(c), 'n.running_var': torch.ones(c)}
+    xr = X.clone().requires_grad_(True)
+    yr = R.sync_bn(sd, 'n', xr, True, True, act='relu')
+    ((yr * DY).sum() / world).backward()
+    ref_dx = xr.grad.chunk(world, 0)[rank] * world          # each rank back-propagates its UNSCALED replica loss
+    e1 = float((dx - ref_dx).abs().max() / ref_dx.abs().max())
+    ref_b = torch.cat([sd['n.weight'].grad, sd['n.bias'].grad])
+    e2 = float((bucket - ref_b).abs().max() / ref_b.abs().max())
+    q.put((rank, e1, e2))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_sync_batchnorm_protocol_world2_gloo():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_syncbn, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+    for _ in range(2):
+        rank, e1, e2 = q.get(timeout=10)
+        assert e1 < 1e-4 and e2 < 1e-4, (rank, e1, e2)

@@ -42,3 +42,39 @@ def test_shrink_matches_reference_bit_exactly(tag, norm, track, target):
     for key in g.files:
         if key.startswith('copied:'):
             assert np.array_equal(ssd[key[7:]].numpy(), g[key]), key      # index selection is bit-exact
+
+
+@pytest.mark.parametrize('tag', ['a', 'b'])
+def test_shrink_spade_bit_exact(tag):
+    """shrink_spade_model's architecture search (utils/common.py:710-812) against the reference's own run
+    (tests/golden/spade_shrink.npz): threshold (float32), searched n_macs, every channel list and the resulting state_dict
+    shapes are integers / bit patterns and must match exactly.  Host-side, runs on CPU (shape propagation, no forward)."""
+    import json
+    from argparse import Namespace
+    from cat_amd import networks
+    from cat_amd.prune import spade_search, model_profiling
+    g = H.load('spade_shrink.npz')
+    o = json.loads(str(g['opt']))
+    o['target_flops'], o['prune_cin_lb'] = float(g[f'{tag}_target']), int(g[f'{tag}_lb'])
+    opt = Namespace(**o)
+    topt = Namespace(**o)
+    topt.ngf, topt.norm_G = opt.teacher_ngf, opt.teacher_norm_G
+    T = networks.define_G(opt.input_nc, 3, opt.teacher_ngf, 'inception_spade', 'instance', 0, 'xavier', 0.02, [], opt=topt)
+    ref_shapes = json.loads(str(g['T_shapes']))
+    assert [k for k, _ in ref_shapes] == list(T.state_dict().keys())
+    T.load_state_dict(detfill.fill_state_dict(T.state_dict(), 112, gamma_abs_normal=True))
+    thr, searched, S, ngf_stu = spade_search(T, opt.target_flops, opt)
+    assert np.float32(float(thr)) == g[f'{tag}_thr'], (float(thr), float(g[f'{tag}_thr']))
+    assert int(searched) == int(g[f'{tag}_n_macs'])
+    cfg = json.loads(str(g[f'{tag}_cfg']))
+    assert S.fc.out_channels == cfg['fc'] and ngf_stu * 16 == cfg['fc']
+    for name, blk in S.get_named_block_list().items():
+        ref = cfg['blocks'][name]
+        got = dict(input_dim=blk.input_dim, output_dim=blk.output_dim, res=blk.res_channels, dw=blk.dw_channels,
+                   spade_res=blk.spade.res_channels, spade_dw=blk.spade.dw_channels, shortcut=blk.shortcut is not None)
+        assert got == ref, (name, got, ref)
+    s_shapes = json.loads(str(g[f'{tag}_S_shapes']))
+    sd = S.state_dict()
+    assert [k for k, _ in s_shapes] == list(sd.keys())
+    assert all(list(sd[k].shape) == shp for k, shp in s_shapes)
+    assert model_profiling(S, opt.data_height, opt.data_width, channel=opt.data_channel)[0] == int(g[f'{tag}_n_macs'])

@@ -222,3 +222,42 @@ def main():
 
 if __name__ == '__main__':
     main()
+
+
+def shrink_golden():
+    """shrink_spade_model (utils/common.py:710-869) run for real on a seeded teacher whose norm scales are |N(0,1)|."""
+    from argparse import Namespace
+    uc.Adam = lambda params, lr, betas: torch.optim.Adam(params, lr=lr, betas=(float(betas[0]), float(betas[1])))   # torch 2.10 rejects int 0
+    out = {}
+    for tag, target, lb in (('a', 0.8e9, 1), ('b', 0.35e9, 2)):
+        opt = spade_opt(target_flops=target, prune_cin_lb=lb, data_height=128, data_width=256, data_channel=6, lr_policy='linear')
+        m = build(opt)
+        m.netG_teacher.load_state_dict(detfill.fill_state_dict(m.netG_teacher.state_dict(), SEED_T + 1, gamma_abs_normal=True))
+        model = Namespace(modules_on_one_gpu=m, device=torch.device('cpu'), isTrain=True,
+                          optimizer_D=torch.optim.Adam(m.netD.parameters(), lr=1e-4, betas=(0.0, 0.9)))
+        import io, contextlib
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            uc.shrink_spade_model(model, target, opt)
+        line = [l for l in buf.getvalue().splitlines() if l.startswith('scale threshold')][0]
+        thr = float(line.split('scale threshold: ')[1].split(',')[0])
+        S = m.netG_student
+        cfg = {'fc': S.fc.out_channels, 'blocks': {}}
+        for name, blk in S.get_named_block_list().items():
+            cfg['blocks'][name] = dict(input_dim=blk.input_dim, output_dim=blk.output_dim, res=blk.res_channels, dw=blk.dw_channels,
+                                       spade_res=blk.spade.res_channels, spade_dw=blk.spade.dw_channels,
+                                       shortcut=blk.shortcut is not None)
+        out[f'{tag}_target'], out[f'{tag}_lb'] = target, lb
+        out[f'{tag}_thr'] = np.float32(thr)
+        out[f'{tag}_n_macs'] = np.int64(S.n_macs)
+        out[f'{tag}_cfg'] = json.dumps(cfg)
+        out[f'{tag}_netA'] = np.array([a.in_channels for a in m.netAs] + [a.out_channels for a in m.netAs])
+        out[f'{tag}_S_shapes'] = shapes_json(S.state_dict())
+        out['T_shapes'] = shapes_json(m.netG_teacher.state_dict())
+        out['opt'] = json.dumps({k: v for k, v in vars(opt).items() if isinstance(v, (int, float, str, bool, list, type(None)))})
+        print('shrink', tag, thr, int(S.n_macs), cfg['fc'], cfg['blocks']['up_1'])
+    np.savez_compressed(os.path.join(OUT, 'spade_shrink.npz'), **out)
+
+
+if __name__ == '__main__' and os.environ.get('GOLDEN_SHRINK', '1') == '1':
+    shrink_golden()
