@@ -58,6 +58,76 @@ def build_model(args, device_index):
     return model, opt
 
 
+def build_spade_model(args, device_index):
+    """BASELINE configs[3]: GauGAN SPADEDistiller.optimize_parameters at 512x256 (crop 512, aspect 2), per-GPU
+    batch 4 -- frozen teacher ngf 64, student ngf 48 pruned by shrink_spade_model to 5.6e9 MACs (the launch script's budget),
+    multiscale spectral-norm PatchGAN ndf 64, hinge + feature matching + VGG + KA.  VGG19 carries random weights of the real
+    topology (no network to fetch torchvision's): same kernels, same FLOPs."""
+    import helpers as H
+    from oracle import detfill
+    from cat_amd import prune
+    from cat_amd.distillers import create_distiller
+    opt = H.make_opt(norm='instance', gpu_ids=[device_index])
+    opt.__dict__.update(dict(
+        distiller='spade', input_nc=35, output_nc=3, semantic_nc=36, contain_dontcare_label=False, no_instance=False,
+        teacher_ngf=64, student_ngf=48, pretrained_ngf=64, teacher_netG='inception_spade', student_netG='inception_spade',
+        pretrained_netG='inception_spade', teacher_norm_G='spadesyncbatch3x3', student_norm_G='spadesyncbatch3x3',
+        pretrained_norm_G='spadesyncbatch3x3', num_upsampling_layers='more', crop_size=2 * args.size, aspect_ratio=2.0,
+        netD='multi_scale', ndf=64, n_layers_D=4, num_D=2, norm_D='spectralinstance', init_type='xavier', init_gain=0.02,
+        gan_mode='hinge', lambda_gan=1.0, lambda_feat=10.0, lambda_vgg=10.0, lambda_distill=0.5, distill_G_loss_type='ka',
+        no_TTUR=False, lr=2e-4, beta1=0.5, beta2=0.999, target_flops=args.target_flops, prune_cin_lb=16,
+        data_height=args.size, data_width=2 * args.size, data_channel=36, restore_pretrained_G_path=None))
+    torch.manual_seed(233)
+    model = create_distiller(opt, verbose=False)
+    m = model.modules_on_one_gpu
+    m.netG_teacher.load_state_dict(detfill.fill_state_dict(m.netG_teacher.state_dict(), 111, gamma_abs_normal=True))
+    model.setup(opt, verbose=False)
+    opt.data_height, opt.data_width = 256, 512          # student shapes are defined at the dataset's size (launch script)
+    prune.shrink(model, opt)
+    m.train()
+    return model, opt
+
+
+def spade_batches(args, rank, nbuf):
+    import numpy as np
+    from oracle import detfill
+    h, w = args.size, 2 * args.size
+    out = []
+    for i in range(nbuf):
+        rng = np.random.default_rng(3000 + 10 * i + rank)
+        lab = np.repeat(np.repeat(rng.integers(0, 35, (args.batch, 1, h // 16, w // 16)), 16, 2), 16, 3).astype(np.int32)
+        ins = np.repeat(np.repeat(rng.integers(0, 1000, (args.batch, 1, h // 16, w // 16)), 16, 2), 16, 3).astype(np.int32)
+        out.append({'label': torch.from_numpy(lab).cuda(), 'instance': torch.from_numpy(ins).cuda(),
+                    'image': detfill.images((args.batch, 3, h, w), 4000 + 10 * i + rank).cuda(), 'path': []})
+    return out
+
+
+def cpu_baseline_spade(opt, model, args):
+    """oracle/ref_spade_cpu.spade_step (a port: plain PyTorch ATen ops) on a bounded sample: batch 1, one warm-up + one timed step."""
+    import numpy as np
+    from oracle import detfill, ref_spade_cpu as R
+    m = model.modules_on_one_gpu
+    cpu = lambda net: {k: v.detach().cpu().contiguous().clone() for k, v in net.state_dict().items()}
+    vsd = {k.split('.', 1)[1]: v for k, v in cpu(m.criterionVGG.vgg).items()}
+    cfg = dict(G=dict(crop_size=opt.crop_size, aspect_ratio=opt.aspect_ratio, num_upsampling_layers=opt.num_upsampling_layers), num_D=2,
+               n_layers_D=4, lambda_gan=1.0, lambda_feat=10.0, lambda_vgg=10.0, lambda_distill=0.5, lr=opt.lr, beta1=0.5, beta2=0.999,
+               no_TTUR=False)
+    st = R.SpadeState(cpu(m.netG_teacher), cpu(m.netG_student), cpu(m.netD), vsd, cfg)
+    h, w = args.size, 2 * args.size
+    rng = np.random.default_rng(5)
+    lab = torch.from_numpy(np.repeat(np.repeat(rng.integers(0, 35, (1, 1, h // 16, w // 16)), 16, 2), 16, 3))
+    ins = torch.from_numpy(np.repeat(np.repeat(rng.integers(0, 1000, (1, 1, h // 16, w // 16)), 16, 2), 16, 3).astype(np.int32))
+    sem = R.preprocess_input(lab, ins, 35)
+    img = detfill.images((1, 3, h, w), 6)
+    cores = torch.get_num_threads()
+    R.spade_step(st, sem, img)
+    t0 = time.perf_counter()
+    R.spade_step(st, sem, img)
+    dt = time.perf_counter() - t0
+    return {'value': round(1 / dt, 4), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
+            'sample': f'oracle/ref_spade_cpu.spade_step, batch 1 @ {w}x{h}, 1 warm-up + 1 timed step, {cores} torch threads'}
+
+
 def cpu_baseline(opt, model, args):
     """The CPU oracle (a port: plain PyTorch ATen ops, same algorithm) on a bounded sample: batch 2 at the bench
     resolution, 1 warm-up + 2 timed steps (~10-30 s of host work)."""
@@ -88,13 +158,22 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=16, help='per-GPU batch (BASELINE: 16)')
-    ap.add_argument('--size', type=int, default=256)
-    ap.add_argument('--target-flops', type=float, default=4.6e9, dest='target_flops')
+    ap.add_argument('--workload', default='c2', choices=['c2', 'spade'],
+                    help='c2 = pix2pix InceptionDistiller (BASELINE configs[1], the headline metric); spade = GauGAN SPADEDistiller '
+                         '(configs[3], per-GPU batch 4 @ 512x256)')
+    ap.add_argument('--batch', type=int, default=None, help='per-GPU batch (default: 16 for c2, 4 for spade)')
+    ap.add_argument('--size', type=int, default=256, help='image height (spade: width = 2 * size)')
+    ap.add_argument('--target-flops', type=float, default=None, dest='target_flops')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-profile', action='store_true')
     ap.add_argument('--no-overlap', action='store_true')
+    ap.add_argument('--graph', type=int, default=1, help='1 (default): replay the step as one captured hipGraph on 1 GPU; 0: eager launches')
     args = ap.parse_args()
+    spade = args.workload == 'spade'
+    if args.batch is None:
+        args.batch = 4 if spade else 16
+    if args.target_flops is None:
+        args.target_flops = 5.6e9 if spade else 4.6e9
 
     from cat_amd import _lib, ops, parallel
     _lib.load()
@@ -106,23 +185,37 @@ def main():
     os.environ['LOCAL_RANK'] = str(local)
     torch.cuda.set_device(local)
     from oracle import detfill
-    model, opt = build_model(args, local)
+    model, opt = (build_spade_model if spade else build_model)(args, local)
     if args.no_overlap:
         model.teacher_side_stream = False
     if world > 1:
-        model.enable_data_parallel(parallel.DataParallelReducer(), overlap=not args.no_overlap)
+        if spade:
+            model.enable_data_parallel(parallel.DataParallelReducer())
+        else:
+            model.enable_data_parallel(parallel.DataParallelReducer(), overlap=not args.no_overlap)
 
     # synthetic batches, resident in HBM before the timed region (global batch = batch * world; this rank's shard)
     nbuf = 4
     batches = []
-    for i in range(nbuf):
+    if spade:
+        batches = spade_batches(args, rank, nbuf)
+    for i in range(0 if spade else nbuf):
         A = detfill.images((args.batch, 3, args.size, args.size), 1000 + 10 * i + rank).cuda()
         B = detfill.images((args.batch, 3, args.size, args.size), 2000 + 10 * i + rank).cuda()
         batches.append({'A': A, 'B': B, 'A_paths': [], 'B_paths': []})
 
-    def step(i):
+    def eager_step(i):
         model.set_input(batches[i % nbuf])
         model.optimize_parameters(i)
+
+    step = eager_step
+    graphed = None
+    if args.graph and world == 1:
+        from cat_amd.graph import GraphedStep
+        graphed = GraphedStep(model, batches[0])
+
+        def step(i):
+            graphed(batches[i % nbuf])
 
     def barrier():
         if world > 1:
@@ -135,7 +228,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
-    if world > 1:
+    if world > 1 and hasattr(model, 'finish_pending'):
         model.finish_pending()
     barrier()
     dt = time.perf_counter() - t0
@@ -147,24 +240,32 @@ def main():
 
     roofline = None
     if not args.no_kernel_profile and rank == 0:
-        roofline = kernel_roofline(model, step, args)
+        roofline = kernel_roofline(model, eager_step, args)
     if world > 1:
         torch.distributed.barrier()
 
     ips = args.batch * world * args.steps / dt
+    if spade:
+        metric = f'distill-step images/sec @{2 * args.size}x{args.size} bs={args.batch} (GauGAN SPADEDistiller)'
+        workload = ('GauGAN SPADEDistiller.optimize_parameters (BASELINE configs[3]): teacher ngf64 frozen + student ngf48 pruned to '
+                    f'{args.target_flops:.2g} MACs + multiscale SN-PatchGAN ndf64, hinge + feat + VGG + KA, TTUR Adam x2')
+        image, n_macs = f'{2 * args.size}x{args.size}', int(model.modules_on_one_gpu.netG_student.n_macs)
+    else:
+        metric = 'distill-step images/sec @256x256 bs=16'
+        workload = ('pix2pix InceptionDistiller.optimize_parameters (BASELINE configs[1]): teacher ngf64 frozen + student '
+                    f'pruned to {args.target_flops:.2g} MACs + PatchGAN ndf128, hinge + L1 + KA, Adam x2')
+        image, n_macs = f'{args.size}x{args.size}', int(model.netG_student.n_macs)
     out = {
-        'metric': 'distill-step images/sec @256x256 bs=16', 'value': round(ips, 3), 'unit': 'images/sec', 'n_gpus': world,
+        'metric': metric, 'value': round(ips, 3), 'unit': 'images/sec', 'n_gpus': world,
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * dt / args.steps, 3), 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': 'pix2pix InceptionDistiller.optimize_parameters (BASELINE configs[1]): teacher ngf64 frozen + student '
-                               f'pruned to {args.target_flops:.2g} MACs + PatchGAN ndf128, hinge + L1 + KA, Adam x2',
-                   'image': f'{args.size}x{args.size}', 'per_gpu_batch': args.batch, 'global_batch': args.batch * world,
-                   'parallelism': f'dp{world}', 'student_n_macs': int(model.netG_student.n_macs)},
+        'config': {'workload': workload, 'image': image, 'per_gpu_batch': args.batch, 'global_batch': args.batch * world,
+                   'parallelism': f'dp{world}', 'student_n_macs': n_macs, 'launch': 'hipGraph replay' if graphed is not None else 'eager'},
         'roofline': roofline,
     }
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(opt, model, args)
+            out['cpu_baseline'] = (cpu_baseline_spade if spade else cpu_baseline)(opt, model, args)
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -37,6 +37,10 @@ SIGNATURES = {
     'cat_conv2d_fwd': (c_i, [_G, c_p, c_p, c_p, c_p, c_p]),
     'cat_conv2d_dgrad': (c_i, [_G, c_p, c_p, c_p, c_p, c_i, c_i, c_p]),
     'cat_conv2d_wgrad_ws_bytes': (C.c_size_t, [_G]),
+    'cat_conv2d_fwd_ws_bytes': (C.c_size_t, [_G]),
+    'cat_conv2d_fwd_ws': (c_i, [_G, c_p, c_p, c_p, c_p, c_p, c_p]),
+    'cat_conv2d_dgrad_ws_bytes': (C.c_size_t, [_G, c_i]),
+    'cat_conv2d_dgrad_ws': (c_i, [_G, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p]),
     'cat_conv2d_wgrad': (c_i, [_G, c_p, c_p, c_p, c_i, c_p, c_p]),
     'cat_dwconv2d_fwd': (c_i, [_G, c_p, c_p, c_p, c_p, c_p]),
     'cat_dwconv2d_dgrad': (c_i, [_G, c_p, c_p, c_p, c_i, c_p]),
@@ -64,6 +68,7 @@ SIGNATURES = {
     'cat_loss_fwd': (c_i, [c_i, c_p, c_p, c_f, c_l, c_i, c_i, c_p, c_p, c_p]),
     'cat_loss_bwd': (c_i, [c_i, c_p, c_p, c_f, c_l, c_i, c_i, c_p, c_f, c_p, c_p]),
     'cat_adam_step': (c_i, [c_p, c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_f, c_i, c_f, c_p]),
+    'cat_adam_step_dev': (c_i, [c_p, c_p, c_p, c_p, c_l, c_p, c_f, c_p]),
     'cat_prof_enable': (None, [c_i]),
     'cat_prof_collect': (c_i, []),
     'cat_prof_family': (c_i, [c_i, C.c_char_p, c_i, C.POINTER(c_l), C.POINTER(C.c_double), C.POINTER(C.c_double)]),

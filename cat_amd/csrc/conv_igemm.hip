@@ -42,6 +42,10 @@ struct IgemmArgs {
   int Hin, Win, pad_eff, ocs;
   // wgrad
   int nsplit, mchunk, direct, accumulate;
+  // split-K (fwd32 / dgrad when the output tile grid cannot fill the chip): blockIdx.y (fwd) / blockIdx.z (dgrad) = K slice of
+  // `kchunks` chunks; raw partial sums go to part[slice][pixel][channel], splitk_reduce_kernel adds bias / activation
+  int ksplit, kchunks;
+  float* part;
   int ablate;  // diagnostics only
   long long* dbg;  // diagnostics only (CAT_DBG): per-phase shader-clock totals of one wave
 };
@@ -301,10 +305,13 @@ __global__ __launch_bounds__(256) void conv_fwd32_kernel(IgemmArgs p) {
     ix0[i] = ox * p.stride - p.pad;
     xoff[i] = (int64_t)n * p.H * p.W * p.xcs;
   }
+  const int nk_all = (p.K + 31) >> 5;   // a trailing half chunk reads zeros (tap >= taps)
+  const int kbeg = p.ksplit > 1 ? (int)blockIdx.y * p.kchunks : 0;
+  const int nk = p.ksplit > 1 ? min(nk_all, kbeg + p.kchunks) - kbeg : nk_all;
   // walk state: tap = (ky, kx), ci = channel of this quad inside the tap; advanced by 32 per chunk
   int tap, ci, ky, kx;
   {
-    const int k = q * 4;
+    const int k = q * 4 + kbeg * 32;
     tap = k / p.c4;
     ci = k - tap * p.c4;
     ky = tap / p.kw;
@@ -408,7 +415,6 @@ __global__ __launch_bounds__(256) void conv_fwd32_kernel(IgemmArgs p) {
     }
   };
 
-  const int nk = (p.K + 31) >> 5;   // a trailing half chunk reads zeros (tap >= taps)
   gload();
   sstore(0);
   __syncthreads();
@@ -422,6 +428,23 @@ __global__ __launch_bounds__(256) void conv_fwd32_kernel(IgemmArgs p) {
   }
   mma((nk - 1) & 1);
 
+  if (p.ksplit > 1) {   // raw partial sums of this K slice
+    float* part = p.part + (int64_t)blockIdx.y * p.M * p.ycs;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int col = n0 + wn * NT * 16 + j * 16 + lr;
+      if (col >= p.Cout) continue;
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int m = m0 + wm * MT * 16 + i * 16 + lq * 4 + rg;
+          if (m < p.M) part[(int64_t)m * p.ycs + col] = acc[i][j][rg];
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int col = n0 + wn * NT * 16 + j * 16 + lr;
@@ -486,7 +509,10 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(IgemmArgs p) {
 
   // incremental K walk (see conv_fwd_kernel): A quad = (tap (jy,jx), co..co+3) of dy; B rows = 16 consecutive k of the chunk
   const bool aligned = (p.c4 & 15) == 0;
-  int ka = q * 4, aco, ajy, ajx;
+  const int nk_all = (K + 15) >> 4;
+  const int kbeg = p.ksplit > 1 ? (int)blockIdx.z * p.kchunks : 0;
+  const int nk = p.ksplit > 1 ? max(0, min(nk_all, kbeg + p.kchunks) - kbeg) : nk_all;
+  int ka = q * 4 + kbeg * 16, aco, ajy, ajx;
   {
     const int tj = p.c4 ? ka / p.c4 : 0;
     aco = ka - tj * p.c4;
@@ -517,8 +543,8 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(IgemmArgs p) {
   for (int i = 0; i < BI; ++i) {
     const int idx = tid + 256 * i;
     const int kr = idx / BQ, nq = idx - kr * BQ;
-    kb[i] = kr < 16 ? kr : (1 << 30);   // rows >= 16 (thread has no work in this slot) never become valid
-    const int kk = kr < 16 ? kr : 0;
+    kb[i] = kr < 16 ? kr + kbeg * 16 : (1 << 30);   // rows >= 16 (thread has no work in this slot) never become valid
+    const int kk = kr < 16 ? kr + kbeg * 16 : 0;
     const int tj = p.c4 ? kk / p.c4 : 0;
     bco[i] = kk - tj * p.c4;
     bjy[i] = ntx ? tj / ntx : 0;
@@ -605,7 +631,6 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(IgemmArgs p) {
     for (int j = 0; j < NT; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
 
   const int lr = lane & 15, lq = lane >> 4;
-  const int nk = (K + 15) >> 4;
   if (nk > 0) {
     gload();
     sstore(0);
@@ -645,7 +670,17 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(IgemmArgs p) {
       if (m >= Mc) continue;
       const int n = m / HcWc, rem = m - n * HcWc;
       const int a = rem / Wc, b = rem - a * Wc;
-      float* orow = p.out + (((int64_t)n * p.Hin + (iyf + a * s)) * p.Win + (ixf + b * s)) * p.ocs;
+      const int64_t opix = (((int64_t)n * p.Hin + (iyf + a * s)) * p.Win + (ixf + b * s)) * p.ocs;
+      if (p.ksplit > 1) {   // raw partial sums of this K slice
+        float* prow = p.part + (int64_t)blockIdx.z * p.N * p.Hin * p.Win * p.ocs + opix;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int col = n0 + wn * NT * 16 + j * 16 + lr;
+          if (col < p.Cin) prow[col] = acc[i][j][rg];
+        }
+        continue;
+      }
+      float* orow = p.out + opix;
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const int col = n0 + wn * NT * 16 + j * 16 + lr;
@@ -887,11 +922,57 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }                                \
   } while (0)
 
+// out[pix][c] = act(sum_z part[z][pix][c] + bias[c]) for c < C; zeros for C <= c < cw
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias,
+                                                            float* __restrict__ out, int64_t P, int C, int cw, int cs, int ksplit, int act,
+                                                            float slope) {
+  const int nq = (cw + 3) >> 2;
+  const int64_t total = P * nq;
+  const int64_t zstride = P * cs;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % nq) * 4;
+    const int64_t off = (i / nq) * cs + c;
+    f4 s = {0.f, 0.f, 0.f, 0.f};
+    if (c < C)
+      for (int z = 0; z < ksplit; ++z) s += *reinterpret_cast<const f4*>(part + z * zstride + off);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (c + e < C) out[off + e] = cat::apply_act(s[e] + (bias ? bias[c + e] : 0.f), act, slope);
+      else if (c + e < cw) out[off + e] = 0.f;
+    }
+  }
+}
+
 static int default_bm(int n) { return n <= 32 ? 256 : 128; }
 static bool use_small_m(int M, int n) {
   static const int mode = getenv("CAT_SMALLM") ? atoi(getenv("CAT_SMALLM")) : 1;
   if (!mode || n > 32) return false;   // measured: helps the 16/32-wide tiles (256-row default), not the 48..96-wide ones
   return cdiv(M, default_bm(n)) < 768;
+}
+
+// Split-K plan: when the (M, N) tile grid of the kernel the dispatcher would pick is far below the 256 CUs (the 4x8 .. 32x64
+// pixel layers of the SPADE generators: M = 128 .. 8192 pixels against K = 25 * 1024), K is cut into slices of >= 4 chunks.
+struct SplitPlan { int ksplit, kchunks; };
+static SplitPlan split_plan(int M, int n, int nk) {
+  SplitPlan p{1, nk};
+  static const int off = getenv("CAT_NO_SPLITK") ? atoi(getenv("CAT_NO_SPLITK")) : 0;
+  const bool smallm = use_small_m(M, n);
+  const int bn = n <= 16 ? 16 : n <= 32 ? 32 : n <= 48 ? 48 : n <= 64 ? 64 : n <= 96 ? 96 : 128;
+  const int bm = n > 96 ? 128 : (smallm ? (n <= 32 ? 128 : 64) : (n <= 32 ? 256 : 128));
+  const int tiles = cdiv(M, bm) * cdiv(n, bn);
+  if (off || tiles >= 128 || nk < 16) return p;
+  int ks = cdiv(512, tiles);
+  if (ks > nk / 4) ks = nk / 4;
+  if (ks < 2) return p;
+  p.kchunks = cdiv(nk, ks);
+  p.ksplit = cdiv(nk, p.kchunks);
+  if (p.ksplit < 2) p = SplitPlan{1, nk};
+  return p;
+}
+
+static int reduce_grid(int64_t n) {
+  int64_t b = (n + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
 }
 
 int fill_common(IgemmArgs& a, const cat_conv_t* g) {
@@ -943,13 +1024,40 @@ WgradPlan wgrad_plan(const cat_conv_t* g) {
 
 extern "C" {
 
-int cat_conv2d_fwd(const cat_conv_t* g, const float* x, const float* w, const float* bias, float* y, cat_stream_t stream) {
-  IgemmArgs a{};
+static bool fwd_bk32_ok(const IgemmArgs& a) {
+  static const int no_bk32 = getenv("CAT_NO_BK32") ? atoi(getenv("CAT_NO_BK32")) : 0;
+  return !no_bk32 && a.wvec && (a.c4 & 15) == 0 && !getenv("CAT_DBG");
+}
+
+static int fwd_setup(IgemmArgs& a, const cat_conv_t* g) {
   if (int e = fill_common(a, g)) return e;
-  a.a = x; a.b = w; a.bias = bias; a.out = y;
   a.cval = (g->Cin + 3) & ~3;
   a.c4 = walk_extent(a.cval);
   a.K = g->kh * g->kw * a.c4;
+  return 0;
+}
+
+size_t cat_conv2d_fwd_ws_bytes(const cat_conv_t* g) {
+  IgemmArgs a{};
+  if (fwd_setup(a, g) || cat::smallco_applicable(g) || !fwd_bk32_ok(a)) return 0;
+  const SplitPlan sp = split_plan(a.M, a.Cout, (a.K + 31) >> 5);
+  return sp.ksplit > 1 ? (size_t)sp.ksplit * a.M * g->ycs * sizeof(float) : 0;
+}
+
+static int conv_fwd_impl(const cat_conv_t* g, const float* x, const float* w, const float* bias, float* y, void* ws, cat_stream_t stream);
+
+int cat_conv2d_fwd(const cat_conv_t* g, const float* x, const float* w, const float* bias, float* y, cat_stream_t stream) {
+  return conv_fwd_impl(g, x, w, bias, y, nullptr, stream);
+}
+
+int cat_conv2d_fwd_ws(const cat_conv_t* g, const float* x, const float* w, const float* bias, float* y, void* ws, cat_stream_t stream) {
+  return conv_fwd_impl(g, x, w, bias, y, ws, stream);
+}
+
+static int conv_fwd_impl(const cat_conv_t* g, const float* x, const float* w, const float* bias, float* y, void* ws, cat_stream_t stream) {
+  IgemmArgs a{};
+  if (int e = fwd_setup(a, g)) return e;
+  a.a = x; a.b = w; a.bias = bias; a.out = y;
   static const int ablate = getenv("CAT_ABLATE") ? atoi(getenv("CAT_ABLATE")) : 0;
   a.ablate = ablate;
   a.cw = g->ycw > g->Cout ? g->ycw : g->Cout;
@@ -978,12 +1086,19 @@ int cat_conv2d_fwd(const cat_conv_t* g, const float* x, const float* w, const fl
     else conv_fwd_kernel<MT, NT, WM, WN, true, 0><<<grid, 256, lds_pad, s>>>(a);            \
   }
   // BK = 32 path: per-tap K extent a multiple of 32 (allowing <= 12.5 % zero padding) and float4-readable filter rows
-  static const int no_bk32 = getenv("CAT_NO_BK32") ? atoi(getenv("CAT_NO_BK32")) : 0;
-  const bool bk32 = !no_bk32 && a.wvec && (a.c4 & 15) == 0 && !a.dbg;   // a.c4 = walk_extent(cval): multiple of 16 when padding <= 12.5 %
+  const bool bk32 = fwd_bk32_ok(a);   // a.c4 = walk_extent(cval): multiple of 16 when padding <= 12.5 %
+  a.ksplit = 1;
+  if (bk32 && ws) {
+    const SplitPlan sp = split_plan(a.M, a.Cout, (a.K + 31) >> 5);
+    a.ksplit = sp.ksplit;
+    a.kchunks = sp.kchunks;
+    a.part = (float*)ws;
+  }
 #define LAUNCH32(MT, NT, WM, WN)                                                                      \
   {                                                                                                   \
-    cat::ProfScope prof("conv_fwd32_" #MT "x" #NT "x" #WM "x" #WN, prof_flops, 0.0, stream);          \
-    const int grid = cdiv(a.M, WM * MT * 16) * cdiv(a.Cout, WN * NT * 16);                            \
+    cat::ProfScope prof(a.ksplit > 1 ? "conv_fwd32sk_" #MT "x" #NT "x" #WM "x" #WN : "conv_fwd32_" #MT "x" #NT "x" #WM "x" #WN, prof_flops, 0.0, \
+                        stream);                                                                      \
+    const dim3 grid(cdiv(a.M, WM * MT * 16) * cdiv(a.Cout, WN * NT * 16), a.ksplit);                   \
     const size_t lds = (size_t)2 * (WM * MT * 16 + WN * NT * 16) * 32 * sizeof(float);                \
     static bool attr_set = false;                                                                     \
     if (!attr_set) {                                                                                  \
@@ -991,6 +1106,9 @@ int cat_conv2d_fwd(const cat_conv_t* g, const float* x, const float* w, const fl
       attr_set = true;                                                                                \
     }                                                                                                 \
     conv_fwd32_kernel<MT, NT, WM, WN><<<grid, 256, lds, s>>>(a);                                       \
+    if (a.ksplit > 1)                                                                                 \
+      splitk_reduce_kernel<<<reduce_grid((int64_t)a.M * ((a.cw + 3) / 4)), 256, 0, s>>>(a.part, a.bias, a.out, a.M, a.Cout, a.cw, a.ycs,   \
+                                                                                         a.ksplit, a.act, a.slope);                    \
   }
   const bool smallm = use_small_m(a.M, a.Cout);
   if (bk32) {
@@ -1014,8 +1132,38 @@ int cat_conv2d_fwd(const cat_conv_t* g, const float* x, const float* w, const fl
   return cat::check_launch("conv2d_fwd");
 }
 
+static SplitPlan dgrad_split(const cat_conv_t* g) {
+  if (g->stride != 1) return SplitPlan{1, 0};
+  const bool refl = g->pad_mode == CAT_PAD_REFLECT;
+  const int Hin = refl ? g->H + 2 * g->pad : g->H, Win = refl ? g->W + 2 * g->pad : g->W;
+  const int c4 = walk_extent((g->Cout + 3) & ~3);
+  return split_plan(g->N * Hin * Win, g->Cin, (g->kh * g->kw * c4 + 15) >> 4);
+}
+
+size_t cat_conv2d_dgrad_ws_bytes(const cat_conv_t* g, int dxcs) {
+  if (g->N <= 0 || g->stride != 1) return 0;
+  const SplitPlan sp = dgrad_split(g);
+  if (sp.ksplit <= 1) return 0;
+  const bool refl = g->pad_mode == CAT_PAD_REFLECT;
+  const int Hin = refl ? g->H + 2 * g->pad : g->H, Win = refl ? g->W + 2 * g->pad : g->W;
+  return (size_t)sp.ksplit * g->N * Hin * Win * dxcs * sizeof(float);
+}
+
+static int conv_dgrad_impl(const cat_conv_t* g, const float* dy, const float* w, const float* bias, float* dx, int dxcs, int dxcw, void* ws,
+                           cat_stream_t stream);
+
 int cat_conv2d_dgrad(const cat_conv_t* g, const float* dy, const float* w, const float* bias, float* dx, int dxcs, int dxcw,
                      cat_stream_t stream) {
+  return conv_dgrad_impl(g, dy, w, bias, dx, dxcs, dxcw, nullptr, stream);
+}
+
+int cat_conv2d_dgrad_ws(const cat_conv_t* g, const float* dy, const float* w, const float* bias, float* dx, int dxcs, int dxcw, void* ws,
+                        cat_stream_t stream) {
+  return conv_dgrad_impl(g, dy, w, bias, dx, dxcs, dxcw, ws, stream);
+}
+
+static int conv_dgrad_impl(const cat_conv_t* g, const float* dy, const float* w, const float* bias, float* dx, int dxcs, int dxcw, void* ws,
+                           cat_stream_t stream) {
   IgemmArgs a{};
   if (int e = fill_common(a, g)) return e;
   a.a = dy; a.b = w; a.bias = bias; a.out = dx;
@@ -1030,11 +1178,24 @@ int cat_conv2d_dgrad(const cat_conv_t* g, const float* dy, const float* w, const
   const int mmax = g->N * cdiv(a.Hin, st) * cdiv(a.Win, st);
   hipStream_t s = (hipStream_t)stream;
   const double prof_flops = 2.0 * (double)g->N * g->Ho * g->Wo * g->Cout * g->kh * g->kw * g->Cin;
+  a.ksplit = 1;
+  if (ws) {
+    const SplitPlan sp = dgrad_split(g);
+    a.ksplit = sp.ksplit;
+    a.kchunks = sp.kchunks;
+    a.part = (float*)ws;
+  }
 #define LAUNCH(MT, NT, WM, WN)                                                             \
   {                                                                                        \
-    cat::ProfScope prof("conv_dgrad_" #MT "x" #NT "x" #WM "x" #WN, prof_flops, 0.0, stream); \
-    dim3 grid(cdiv(mmax, WM * MT * 16) * cdiv(a.Cin, WN * NT * 16), st * st);              \
+    cat::ProfScope prof(a.ksplit > 1 ? "conv_dgradsk_" #MT "x" #NT "x" #WM "x" #WN : "conv_dgrad_" #MT "x" #NT "x" #WM "x" #WN, prof_flops, 0.0, \
+                        stream);                                                           \
+    dim3 grid(cdiv(mmax, WM * MT * 16) * cdiv(a.Cin, WN * NT * 16), st * st, a.ksplit);    \
     conv_dgrad_kernel<MT, NT, WM, WN><<<grid, 256, 0, s>>>(a);                              \
+    if (a.ksplit > 1) {                                                                    \
+      const int64_t P = (int64_t)g->N * a.Hin * a.Win;                                     \
+      splitk_reduce_kernel<<<reduce_grid(P * ((a.cw + 3) / 4)), 256, 0, s>>>(a.part, a.bias, a.out, P, a.Cin, a.cw, a.ocs, a.ksplit, a.act,  \
+                                                                            a.slope);      \
+    }                                                                                      \
   }
   if (use_small_m(mmax, a.Cin)) DISPATCH_TILE_N_SMALLM(a.Cin, LAUNCH);
   else DISPATCH_TILE_N(a.Cin, LAUNCH);

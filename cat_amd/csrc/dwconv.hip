@@ -7,7 +7,7 @@
 namespace {
 using cat::cdiv;
 
-constexpr int MAXW = 49 * 64;  // taps * cs floats of LDS filter (k<=7, cs<=64) -- larger problems fall back to global reads
+constexpr int MAXW = 16384;  // taps * cs floats of LDS filter (dynamic LDS, <= 64 KB): k=5 up to 652 channels, k=7 up to 332
 
 struct DwArgs {
   const float* x; const float* w; const float* bias; float* y;
@@ -23,7 +23,7 @@ __device__ __forceinline__ void load_filter(float* sw, const float* w, int C, in
 }
 
 __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs p) {
-  __shared__ __attribute__((aligned(16))) float sw[MAXW];
+  extern __shared__ __attribute__((aligned(16))) float sw[];
   const int taps = p.kh * p.kw, nq = p.ycs / 4;
   load_filter(sw, p.w, p.C, p.ycs, taps);
   const int64_t total = (int64_t)p.N * p.Ho * p.Wo * nq;
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs p) {
 
 // dxp[n,py,px,c] = sum_k dy[n, py+pe-ky, px+pe-kx, c] * w[c,ky,kx]; (Hin,Win,pe) = (H+2p,W+2p,0) for reflect, (H,W,p) for zero pad.
 __global__ __launch_bounds__(256) void dw_dgrad_kernel(DwArgs p, int Hin, int Win, int pe, int dxcs) {
-  __shared__ __attribute__((aligned(16))) float sw[MAXW];
+  extern __shared__ __attribute__((aligned(16))) float sw[];
   const int taps = p.kh * p.kw, nq = dxcs / 4;
   load_filter(sw, p.w, p.C, dxcs, taps);
   const int64_t total = (int64_t)p.N * Hin * Win * nq;
@@ -189,7 +189,7 @@ int cat_dwconv2d_fwd(const cat_conv_t* g, const float* x, const float* w, const 
   DwArgs a = dw_args(g);
   a.x = x; a.w = w; a.bias = bias; a.y = y;
   cat::ProfScope prof("dwconv_fwd", 2.0 * g->N * g->Ho * g->Wo * g->Cin * g->kh * g->kw, 2 * 4.0 * (double)g->N * g->Ho * g->Wo * g->ycs, stream);
-  dw_fwd_kernel<<<ew_grid((int64_t)g->N * g->Ho * g->Wo * (g->ycs / 4)), 256, 0, (hipStream_t)stream>>>(a);
+  dw_fwd_kernel<<<ew_grid((int64_t)g->N * g->Ho * g->Wo * (g->ycs / 4)), 256, (size_t)g->kh * g->kw * g->ycs * sizeof(float), (hipStream_t)stream>>>(a);
   return cat::check_launch("dwconv2d_fwd");
 }
 
@@ -201,7 +201,8 @@ int cat_dwconv2d_dgrad(const cat_conv_t* g, const float* dy, const float* w, flo
   cat::ProfScope prof("dwconv_dgrad", 2.0 * g->N * g->Ho * g->Wo * g->Cin * g->kh * g->kw, 2 * 4.0 * (double)g->N * g->Ho * g->Wo * g->ycs, stream);
   const bool refl = g->pad_mode == CAT_PAD_REFLECT;
   const int Hin = refl ? g->H + 2 * g->pad : g->H, Win = refl ? g->W + 2 * g->pad : g->W, pe = refl ? 0 : g->pad;
-  dw_dgrad_kernel<<<ew_grid((int64_t)g->N * Hin * Win * (dxcs / 4)), 256, 0, (hipStream_t)stream>>>(a, Hin, Win, pe, dxcs);
+  dw_dgrad_kernel<<<ew_grid((int64_t)g->N * Hin * Win * (dxcs / 4)), 256, (size_t)g->kh * g->kw * dxcs * sizeof(float), (hipStream_t)stream>>>(a, Hin, Win, pe,
+                                                                                                                                            dxcs);
   return cat::check_launch("dwconv2d_dgrad");
 }
 

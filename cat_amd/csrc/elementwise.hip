@@ -122,6 +122,33 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   }
 }
 
+// Device-resident optimiser state (hipGraph-replayable step): h = [lr, beta1, beta2, eps, weight_decay, step, step_size, 1/sqrt(bc2)].
+// One thread advances the step counter and derives the bias corrections exactly as cat_adam_step does on the host.
+__global__ void adam_tick_kernel(float* __restrict__ h) {
+  const double step = (double)h[5] + 1.0;
+  const double bc1 = 1.0 - pow((double)h[1], step);
+  const double bc2 = 1.0 - pow((double)h[2], step);
+  h[5] = (float)step;
+  h[6] = (float)((double)h[0] / bc1);
+  h[7] = (float)(1.0 / sqrt(bc2));
+}
+
+__global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                       float* __restrict__ v, int64_t n, const float* __restrict__ h, float gscale) {
+  const float b1 = h[1], b2 = h[2], eps = h[3], wd = h[4], step_size = h[6], inv_bc2_sqrt = h[7];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    float gi = g[i] * gscale;
+    const float pi = p[i];
+    if (wd != 0.f) gi += wd * pi;
+    const float mi = m[i] + (gi - m[i]) * (1.f - b1);
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) * inv_bc2_sqrt + eps;
+    p[i] = pi - step_size * (mi / denom);
+  }
+}
+
 // per-channel sums over pixels, two deterministic stages
 __global__ __launch_bounds__(256) void chansum_partial_kernel(const float* __restrict__ x, float* __restrict__ part, int64_t M, int cs,
                                                               int zq, int ppl, int nb) {
@@ -290,6 +317,15 @@ int cat_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float
   const float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
   adam_kernel<<<ew_grid(n), 256, 0, (hipStream_t)stream>>>(p, g, m, v, n, beta1, beta2, eps, weight_decay, step_size, inv_bc2_sqrt,
                                                             grad_scale);
+  return cat::check_launch("adam");
+}
+
+int cat_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, float* hyper, float grad_scale, cat_stream_t stream) {
+  cat::ProfScope prof("adam", 0.0, 28.0 * n, stream);
+  CAT_REQUIRE(hyper, "adam: device hyper-parameter block required");
+  hipStream_t s = (hipStream_t)stream;
+  adam_tick_kernel<<<1, 1, 0, s>>>(hyper);
+  if (n > 0) adam_dev_kernel<<<ew_grid(n), 256, 0, s>>>(p, g, m, v, n, hyper, grad_scale);
   return cat::check_launch("adam");
 }
 

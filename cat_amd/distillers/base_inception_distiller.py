@@ -209,6 +209,7 @@ class BaseInceptionDistiller:
         self.loss_D_real = self.criterionGAN(pred_real, True, for_discriminator=True)
         self.loss_D = LossValue([(0.5, self.loss_D_fake), (0.5, self.loss_D_real)])
         torch.autograd.backward([self.loss_D_fake, self.loss_D_real], [self.seed(0.5), self.seed(0.5)])
+        ops.sync_side_streams()
 
     # -- bookkeeping shared with models/base_model.py:146-232 -------------------------------------------------
     def set_requires_grad(self, nets, requires_grad=False):

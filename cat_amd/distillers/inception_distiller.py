@@ -93,6 +93,7 @@ class InceptionDistiller(BaseInceptionDistiller):
             self.loss_G_distill = 0
         self.loss_G = self.loss_G_gan + self.loss_G_recon + self.loss_G_distill
         torch.autograd.backward(terms, seeds)
+        ops.sync_side_streams()
 
     def optimize_parameters(self, steps):
         """forward -> D step -> G step (inception_distiller.py:179-188).  Optionally (`teacher_side_stream`) the frozen teacher's

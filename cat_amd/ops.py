@@ -92,14 +92,46 @@ def set_branch_streams(on):
     _BRANCH_STREAMS = bool(on)
 
 
+class _BranchOutFn(torch.autograd.Function):
+    """Identity at the end of a side-stream branch.  Its backward runs on that side stream and receives a gradient that was
+    allocated on the MAIN stream (the branch sum's gradient, shared by all branches): mark it as in use here, otherwise the caching
+    allocator may hand the block to the next main-stream kernel while this branch is still reading it."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy.record_stream(torch.cuda.current_stream())
+        return dy
+
+
+_USED = {}
+
+
+def sync_side_streams():
+    """Make the current stream wait for every side stream that ran branch work since the last call.  Must follow each backward
+    pass: weight-gradient kernels write straight into the optimiser's flat buffer from the branch streams, and a branch whose input
+    needs no gradient (the SPADE gamma/beta branches read the segmentation map) ends there -- nothing downstream would otherwise
+    order the optimiser step (or a captured graph's next node) after them."""
+    main = torch.cuda.current_stream()
+    used = _USED.pop((main.device, main.cuda_stream), None)
+    if used:
+        for st in used:
+            main.wait_stream(st)
+
+
 def run_on_side_streams(fns, inputs):
     main = torch.cuda.current_stream()
     dev = inputs[0].device
     key = (dev, main.cuda_stream)
+    _USED.setdefault(key, set()).update(_SIDE.get(key, [])[:len(fns)])
     pool = _SIDE.get(key)
     if pool is None or len(pool) < len(fns):
         pool = [torch.cuda.Stream(device=dev) for _ in range(max(len(fns), 6))]
         _SIDE[key] = pool
+    _USED[key].update(pool[:len(fns)])
     fork = main.record_event()
     outs = []
     for fn, xi, st in zip(fns, inputs, pool):
@@ -107,6 +139,8 @@ def run_on_side_streams(fns, inputs):
         xi.record_stream(st)
         with torch.cuda.stream(st):
             o = fn(xi)
+            if o.requires_grad:
+                o = _BranchOutFn.apply(o)
         o.record_stream(main)
         main.wait_event(st.record_event())
         outs.append(o)
@@ -222,6 +256,23 @@ def _nchw(t):
 
 
 # ---------------------------------------------------------------------------------------------- convolutions
+def _conv_fwd(g, x, w, bias, y, st):
+    """cat_conv2d_fwd, or its split-K variant when the layer's tile grid is too small for the chip."""
+    nb = L.query('cat_conv2d_fwd_ws_bytes', C.byref(g))
+    if nb:
+        L.call('cat_conv2d_fwd_ws', C.byref(g), _p(x), _p(w), _p(bias), _p(y), _p(workspace(nb, y.device)), st)
+    else:
+        L.call('cat_conv2d_fwd', C.byref(g), _p(x), _p(w), _p(bias), _p(y), st)
+
+
+def _conv_dgrad(g, dy, w, bias, dx, dxcs, dxcw, st):
+    nb = L.query('cat_conv2d_dgrad_ws_bytes', C.byref(g), dxcs)
+    if nb:
+        L.call('cat_conv2d_dgrad_ws', C.byref(g), _p(dy), _p(w), _p(bias), _p(dx), dxcs, dxcw, _p(workspace(nb, dx.device)), st)
+    else:
+        L.call('cat_conv2d_dgrad', C.byref(g), _p(dy), _p(w), _p(bias), _p(dx), dxcs, dxcw, st)
+
+
 class Conv2dFn(torch.autograd.Function):
     """nn.Conv2d (+ preceding ReflectionPad2d, + following pointwise activation)."""
 
@@ -238,7 +289,7 @@ class Conv2dFn(torch.autograd.Function):
         wo = (w + 2 * pad - kw) // stride + 1
         y = empty_act(n, cout, ho, wo, x.device)
         g = _conv_geom(n, h, w, cin, act_cs(x), ho, wo, cout, act_cs(y), kh, kw, stride, pad, pad_mode, act, slope, act_cs(y), wcs)
-        L.call('cat_conv2d_fwd', C.byref(g), _p(x), _p(wcl), _p(bias), _p(y), _stream())
+        _conv_fwd(g, x, wcl, bias, y, _stream())
         ctx.geom = (n, h, w, cin, act_cs(x), ho, wo, cout, act_cs(y), kh, kw, stride, pad, pad_mode, wcs)
         ctx.act, ctx.slope = act, slope
         ctx.weight, ctx.bias = weight, bias
@@ -258,12 +309,12 @@ class Conv2dFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if pad_mode == L.PAD_REFLECT and pad > 0:
                 dxp = empty_act(n, cin, h + 2 * pad, w + 2 * pad, x.device)
-                L.call('cat_conv2d_dgrad', C.byref(g), _p(dy), _p(wcl), None, _p(dxp), act_cs(dxp), act_cs(dxp), st)
+                _conv_dgrad(g, dy, wcl, None, dxp, act_cs(dxp), act_cs(dxp), st)
                 dx = empty_act(n, cin, h, w, x.device)
                 L.call('cat_reflect_pad_bwd', _p(dxp), _p(dx), n, h, w, cin, act_cs(dx), pad, st)
             else:
                 dx = empty_act(n, cin, h, w, x.device)
-                L.call('cat_conv2d_dgrad', C.byref(g), _p(dy), _p(wcl), None, _p(dx), act_cs(dx), act_cs(dx), st)
+                _conv_dgrad(g, dy, wcl, None, dx, act_cs(dx), act_cs(dx), st)
         if ctx.needs_input_grad[1]:
             ws = workspace(L.query('cat_conv2d_wgrad_ws_bytes', C.byref(g)), x.device)
 

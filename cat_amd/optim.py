@@ -71,7 +71,7 @@ class FusedAdam(torch.optim.Optimizer):
                 p._cat_grad_state = {'fresh': True}
                 p.grad = gv
             flats.append(dict(p=fp, g=fg, m=torch.zeros_like(fp), v=torch.zeros_like(fp), n=total, step=0, params=params,
-                              offs=offs))
+                              offs=offs, hyper=torch.zeros(8, device=dev, dtype=torch.float32), hyper_host=None))
         self._flat = flats
 
     def _ensure_flat(self):
@@ -103,11 +103,26 @@ class FusedAdam(torch.optim.Optimizer):
         for group, f in zip(self.param_groups, self._ensure_flat()):
             if f is None:
                 continue
-            f['step'] += 1
             b1, b2 = group['betas']
-            L.call('cat_adam_step', C.c_void_p(f['p'].data_ptr()), C.c_void_p(f['g'].data_ptr()), C.c_void_p(f['m'].data_ptr()),
-                   C.c_void_p(f['v'].data_ptr()), f['n'], float(group['lr']), float(b1), float(b2), float(group['eps']),
-                   float(group['weight_decay']), f['step'], float(self.grad_scale), stream)
+            # optimiser scalars live in HBM (hipGraph-replayable): the host only rewrites them when a value changed (LambdaLR)
+            host = (float(group['lr']), float(b1), float(b2), float(group['eps']), float(group['weight_decay']), float(f['step']))
+            if f['hyper_host'] != host:
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError('FusedAdam: hyper-parameters changed inside a graph capture; run one eager step first')
+                f['hyper'].copy_(torch.tensor(list(host) + [0.0, 0.0], dtype=torch.float32), non_blocking=False)
+            if not torch.cuda.is_current_stream_capturing():     # a capture records the launch, it does not run it
+                f['step'] += 1
+                f['hyper_host'] = host[:5] + (float(f['step']),)
+            L.call('cat_adam_step_dev', C.c_void_p(f['p'].data_ptr()), C.c_void_p(f['g'].data_ptr()), C.c_void_p(f['m'].data_ptr()),
+                   C.c_void_p(f['v'].data_ptr()), f['n'], C.c_void_p(f['hyper'].data_ptr()), float(self.grad_scale), stream)
+
+    def note_graph_replay(self):
+        """A captured step was replayed: the device-side step counter advanced, keep the host mirror in sync."""
+        for f in self._ensure_flat():
+            if f is not None:
+                f['step'] += 1
+                if f['hyper_host'] is not None:
+                    f['hyper_host'] = f['hyper_host'][:5] + (float(f['step']),)
 
     # -- checkpoint interchange (torch.optim.Adam state_dict layout) ----------------------------------------
     def state_dict(self):

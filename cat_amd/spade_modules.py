@@ -68,6 +68,7 @@ class LossValue:
                 self._SEEDS[key] = s
             seeds.append(s)
         torch.autograd.backward([t for _, t in terms], seeds)
+        ops.sync_side_streams()
 
 
 class SPADEDistillerModules(nn.Module):

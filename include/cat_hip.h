@@ -59,6 +59,15 @@ int cat_conv2d_dgrad(const cat_conv_t* g, const float* dy, const float* w, const
 size_t cat_conv2d_wgrad_ws_bytes(const cat_conv_t* g);
 int cat_conv2d_wgrad(const cat_conv_t* g, const float* x, const float* dy, float* dw, int accumulate, void* ws,
                      cat_stream_t stream);
+/* Split-K variants for layers whose output tile grid cannot fill 256 CUs (few pixels, very deep reduction: the 4x8 .. 32x64
+ * blocks of the SPADE generators, inception_spade_generator.py:63-124).  *_ws_bytes returns 0 when the plain entry point is
+ * the right one; otherwise the caller provides that much scratch and the library reduces the K slices (+ bias, activation). */
+size_t cat_conv2d_fwd_ws_bytes(const cat_conv_t* g);
+int cat_conv2d_fwd_ws(const cat_conv_t* g, const float* x, const float* w, const float* bias, float* y, void* ws,
+                      cat_stream_t stream);
+size_t cat_conv2d_dgrad_ws_bytes(const cat_conv_t* g, int dxcs);
+int cat_conv2d_dgrad_ws(const cat_conv_t* g, const float* dy, const float* w, const float* bias, float* dx, int dxcs,
+                        int dxcw, void* ws, cat_stream_t stream);
 
 /* Depthwise conv (groups == C), stride 1, weights [C][kh][kw]; replaces the groups=midp ConvBNReLU conv at
  * inception_modules.py:166-173.  dgrad for reflect padding again yields the padded-input gradient. */
@@ -145,6 +154,11 @@ int cat_loss_bwd(int kind, const float* a, const float* b, float target, int64_t
  * p, g, m, v: n floats; step = 1-based step count. */
 int cat_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                   float eps, float weight_decay, int step, float grad_scale, cat_stream_t stream);
+/* Same update with the optimiser scalars resident in HBM: hyper = float[8] {lr, beta1, beta2, eps, weight_decay, step,
+ * (derived) lr/bc1, (derived) 1/sqrt(bc2)}.  The call first advances hyper[5] by one and refreshes the derived entries on
+ * the device, so a captured hipGraph of the whole training step can be replayed without touching host state. */
+int cat_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, float* hyper, float grad_scale,
+                      cat_stream_t stream);
 /* Measurement hook (bench.py `roofline`): while enabled, every entry point brackets what it enqueues with a HIP event
  * pair on the caller's stream, tagged with a kernel-family name and its algorithmic FLOPs.  cat_prof_collect()
  * synchronises and folds the records per family; cat_prof_family(i, ...) reads family i (count, total ms, total FLOPs). */

@@ -1,0 +1,82 @@
+"""hipGraph replay of the whole distillation step (cat_amd.graph.GraphedStep) must reproduce the eager launch sequence:
+same kernels, same order, deterministic reductions -> identical losses and weights."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+import helpers as H
+from oracle import detfill
+
+pytestmark = pytest.mark.gpu
+
+
+def _max_param_diff(a, b):
+    worst = 0.0
+    for (ka, va), (kb, vb) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert ka == kb
+        if va.dtype.is_floating_point:
+            scale = max(float(vb.abs().max()), 1e-6)
+            worst = max(worst, float((va - vb).abs().max()) / scale)
+    return worst
+
+
+def test_graph_replay_equals_eager_inception():
+    from cat_amd.graph import GraphedStep
+    g = H.load('step_bn.npz')
+    meta = json.loads(str(g['meta']))
+
+    def build():
+        opt = H.make_opt(norm=meta['norm'], track=meta['track'], ndf=meta['ndf'], dataset_mode=meta['dataset_mode'], gan_mode=meta['gan_mode'],
+                         lambda_recon=meta['lambda_recon'], lambda_distill=meta['lambda_distill'], student_ngf=16)
+        return H.build_distiller(opt, g['student_shapes'])
+    n, s = meta['nbatch'], meta['size']
+    batches = [{'A': detfill.images((n, 3, s, s), 500 + i).cuda(), 'B': detfill.images((n, 3, s, s), 600 + i).cuda(), 'A_paths': [], 'B_paths': []}
+               for i in range(3)]
+    eager, graphed = build(), build()
+    for i in range(3):                       # GraphedStep's warm-up: 3 eager steps on the example batch
+        eager.set_input(batches[0])
+        eager.optimize_parameters(i)
+    step = GraphedStep(graphed, batches[0], warmup=3)
+    for i in (1, 2, 1):
+        eager.set_input(batches[i])
+        eager.optimize_parameters(3 + i)
+        step(batches[i])
+        le, lg = eager.get_current_losses(), graphed.get_current_losses()
+        for k in le:
+            assert abs(le[k] - lg[k]) <= 1e-5 * max(1.0, abs(le[k])), (k, le[k], lg[k])
+    assert _max_param_diff(graphed.netG_student, eager.netG_student) < 1e-5
+    assert _max_param_diff(graphed.netD, eager.netD) < 1e-5
+    assert graphed.optimizer_G._flat[0]['step'] == eager.optimizer_G._flat[0]['step'] == 6
+    assert float(graphed.optimizer_G._flat[0]['hyper'][5]) == 6.0
+
+
+def test_graph_replay_equals_eager_spade():
+    import test_spade_gpu as TS
+    from cat_amd.graph import GraphedStep
+    g, opt, lab, ins, img, sds, cfg = TS.fixture()
+    opt.isTrain, opt.distiller, opt.log_dir = True, 'spade', '/tmp/cat_amd_logs'
+    rng = np.random.default_rng(9)
+    h, w, n = int(g['h']), int(g['w']), int(g['n'])
+    batches = []
+    for i in range(3):
+        lab_i = np.repeat(np.repeat(rng.integers(0, opt.input_nc, (n, 1, h // 16, w // 16)), 16, 2), 16, 3).astype(np.int32)
+        ins_i = np.repeat(np.repeat(rng.integers(0, 99, (n, 1, h // 16, w // 16)), 16, 2), 16, 3).astype(np.int32)
+        batches.append({'label': torch.from_numpy(lab_i).cuda(), 'instance': torch.from_numpy(ins_i).cuda(),
+                        'image': detfill.images((n, 3, h, w), 700 + i).cuda(), 'path': []})
+    eager, graphed = TS.build_spade_distiller(opt, sds), TS.build_spade_distiller(opt, sds)
+    for i in range(3):
+        eager.set_input(batches[0])
+        eager.optimize_parameters(i)
+    step = GraphedStep(graphed, batches[0], warmup=3)
+    for i in (1, 2):
+        eager.set_input(batches[i])
+        eager.optimize_parameters(3 + i)
+        step(batches[i])
+        le, lg = eager.get_current_losses(), graphed.get_current_losses()
+        for k in le:
+            assert abs(le[k] - lg[k]) <= 1e-5 * max(1.0, abs(le[k])), (k, le[k], lg[k])
+    me, mg = eager.modules_on_one_gpu, graphed.modules_on_one_gpu
+    assert _max_param_diff(mg.netG_student, me.netG_student) < 1e-5
+    assert _max_param_diff(mg.netD, me.netD) < 1e-5

@@ -54,6 +54,13 @@ CONV_CASES = [
     (82, 100, 3, 1, 1, False, 0, 1, 10, 10),
     (130, 17, 1, 1, 0, False, 0, 1, 8, 8),
     (5, 5, 3, 2, 1, False, 0, 1, 7, 9),       # odd sizes, stride 2
+    # few pixels, deep reduction (SPADE generator heads): split-K forward and dgrad
+    (1024, 170, 5, 1, 2, False, 2, 4, 4, 8),
+    (170, 1024, 3, 1, 1, False, 0, 2, 8, 16),
+    (256, 23, 5, 1, 2, False, 0, 4, 4, 8),
+    (512, 31, 1, 1, 0, False, 0, 2, 8, 8),
+    (7, 512, 5, 1, 2, False, 0, 4, 4, 8),
+    (96, 16, 3, 1, 1, True, 0, 1, 6, 6),
 ]
 
 
@@ -107,7 +114,7 @@ def test_conv_transpose2d(dev, cin, cout, n, h, w):
 
 
 @pytest.mark.parametrize('c,k,reflect,n,h,w', [(11, 3, True, 2, 12, 10), (14, 5, True, 2, 9, 9), (8, 1, False, 2, 6, 6), (42, 5, True, 1, 16, 16),
-                                               (17, 3, False, 1, 7, 5)])
+                                               (17, 3, False, 1, 7, 5), (170, 5, False, 2, 8, 16), (128, 7, False, 1, 9, 9)])
 def test_depthwise_conv(dev, c, k, reflect, n, h, w):
     from cat_amd import ops
     pad = (k - 1) // 2
