@@ -23,8 +23,8 @@ NormPlan plan(const cat_norm_t* g) {
   p.nz = cdiv(p.nq, 256);
   p.zq = cdiv(p.nq, p.nz);  // quads per z-block (<= 256)
   p.ppl = 256 / p.zq;
-  int nb = cdiv(1024, p.G * p.nz);
-  if (nb > 256) nb = 256;
+  int nb = cdiv(2048, p.G * p.nz);
+  if (nb > 1024) nb = 1024;
   const int maxb = cdiv(p.Pg, p.ppl * 16);
   if (nb > maxb) nb = maxb;
   if (nb < 1) nb = 1;

@@ -453,13 +453,17 @@ __global__ __launch_bounds__(256) void onehot_edges_kernel(const int* __restrict
 // ------------------------------------------------------------------------------------------ spectral normalisation
 // Weight matrix W_mat = weight.view(O, -1) in TORCH order (column j = (i, kh, kw)); storage is [O][taps][wcs].
 // v is kept in torch order (state_dict 'weight_v'), vp is its copy in storage order (zero on padding lanes).
+// t[z][j] = sum over the z-th slice of rows o of W[o][j] * u[o]   (grid (cdiv(Kp,256), SN_OSPLIT); sn_norm_v_kernel adds the slices)
+constexpr int SN_OSPLIT = 16;
 __global__ __launch_bounds__(256) void sn_wt_u_kernel(const float* __restrict__ w, const float* __restrict__ u, float* __restrict__ t, int O,
                                                       int Kp) {
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j >= Kp) return;
+  const int per = (O + SN_OSPLIT - 1) / SN_OSPLIT;
+  const int o0 = blockIdx.y * per, o1 = min(O, o0 + per);
   float s = 0.f;
-  for (int o = 0; o < O; ++o) s += w[(int64_t)o * Kp + j] * u[o];
-  t[j] = s;
+  for (int o = o0; o < o1; ++o) s += w[(int64_t)o * Kp + j] * u[o];
+  t[(int64_t)blockIdx.y * Kp + j] = s;
 }
 
 __device__ float block_sum(float v, float* red) {
@@ -474,12 +478,17 @@ __device__ float block_sum(float v, float* red) {
 }
 
 // v = t / max(||t||, eps), written both in storage order (vp) and torch order (v)
-__global__ __launch_bounds__(1024) void sn_norm_v_kernel(const float* __restrict__ t, float* __restrict__ vp, float* __restrict__ v, int I,
+__global__ __launch_bounds__(1024) void sn_norm_v_kernel(float* __restrict__ t, float* __restrict__ vp, float* __restrict__ v, int I,
                                                          int taps, int wcs, float eps) {
   __shared__ float red[16];
   const int Kp = taps * wcs;
   float s = 0.f;
-  for (int j = threadIdx.x; j < Kp; j += blockDim.x) s += (j % wcs) < I ? t[j] * t[j] : 0.f;
+  for (int j = threadIdx.x; j < Kp; j += blockDim.x) {
+    float a = 0.f;
+    for (int z = 0; z < SN_OSPLIT; ++z) a += t[(int64_t)z * Kp + j];
+    t[j] = a;      // slice 0 now holds the full W^T u (each j is owned by one thread)
+    s += (j % wcs) < I ? a * a : 0.f;
+  }
   const float nrm = sqrtf(block_sum(s, red));
   const float inv = 1.f / fmaxf(nrm, eps);
   for (int j = threadIdx.x; j < Kp; j += blockDim.x) {
@@ -749,17 +758,17 @@ int cat_onehot_edges(const int* label, const int* inst, float* y, int N, int H, 
   return cat::check_launch("onehot_edges");
 }
 
-size_t cat_spectral_norm_ws_bytes(int O, int I, int taps, int wcs) { return ((size_t)2 * taps * wcs + O + 1024) * sizeof(float); }
+size_t cat_spectral_norm_ws_bytes(int O, int I, int taps, int wcs) { return ((size_t)(SN_OSPLIT + 1) * taps * wcs + O + 1024) * sizeof(float); }
 
 int cat_spectral_norm_fwd(const float* w, int O, int I, int taps, int wcs, float* u, float* v, int power_iter, float eps, float* sigma,
                           float* w_sn, float* vp, void* ws, cat_stream_t stream) {
   CAT_REQUIRE(wcs % 4 == 0 && wcs >= I && O > 0 && taps > 0 && u && v && sigma && w_sn && vp && ws, "spectral_norm_fwd: bad arguments");
   hipStream_t s = (hipStream_t)stream;
   const int Kp = taps * wcs;
-  float* t = (float*)ws;        // [Kp]
-  float* sv = t + Kp;           // [O]
+  float* t = (float*)ws;                    // [SN_OSPLIT][Kp]
+  float* sv = t + (size_t)SN_OSPLIT * Kp;   // [O]
   if (power_iter) {
-    sn_wt_u_kernel<<<cdiv(Kp, 256), 256, 0, s>>>(w, u, t, O, Kp);
+    sn_wt_u_kernel<<<dim3(cdiv(Kp, 256), SN_OSPLIT), 256, 0, s>>>(w, u, t, O, Kp);
     sn_norm_v_kernel<<<1, 1024, 0, s>>>(t, vp, v, I, taps, wcs, eps);
     sn_w_v_kernel<<<O, 256, 0, s>>>(w, vp, sv, Kp);
     sn_norm_u_kernel<<<1, 1024, 0, s>>>(sv, u, sigma, O, eps);

@@ -190,7 +190,7 @@ class ConvTranspose2d(nn.ConvTranspose2d):
 
 
 class _NormMixin:
-    def _run(self, x, mode, use_batch_stats, fuse_act):
+    def _run(self, x, mode, use_batch_stats, fuse_act, count_batches=True):
         if isinstance(x, Padded):
             raise NotImplementedError('padding in front of a norm layer')
         act, slope = _act_code(fuse_act)
@@ -200,7 +200,8 @@ class _NormMixin:
                 rm, rv = self.running_mean, self.running_var
                 if self.momentum is None:
                     raise NotImplementedError('cumulative-average BatchNorm (momentum=None)')
-                self.num_batches_tracked.add_(1)
+                if count_batches:
+                    self.num_batches_tracked.add_(1)
             return ops.NormActFn.apply(x, self.weight, self.bias, rm, rv, mode, float(self.eps),
                                        float(self.momentum if self.momentum is not None else 0.0), act, slope)
         scale, shift = ops.bn_fold(self.weight, self.bias, self.running_mean, self.running_var, float(self.eps))
@@ -280,6 +281,8 @@ class SynchronizedBatchNorm2d(BatchNorm2d):
         if isinstance(x, Padded):
             raise NotImplementedError('padding in front of a norm layer')
         if self.training or not self.track_running_stats:
+            if ops.bn_sync() is None:     # one rank: F.batch_norm (batchnorm.py:69-72) = the fused stats/finalize/apply launch
+                return self._run(x, L.NORM_BATCH, True, fuse_act, count_batches=False)
             act, slope = _act_code(fuse_act)
             track = self.training and self.track_running_stats
             return ops.SyncBNFn.apply(x, self.weight, self.bias, self.running_mean if track else None,
