@@ -103,7 +103,7 @@ def spade_batches(args, rank, nbuf):
 
 
 def cpu_baseline_spade(opt, model, args):
-    """oracle/ref_spade_cpu.spade_step (a port: plain PyTorch ATen ops) on a bounded sample: batch 1, one warm-up + one timed step."""
+    """oracle/ref_spade_cpu.spade_step (a port: plain PyTorch ATen ops) on a bounded sample: batch 1, one timed step."""
     import numpy as np
     from oracle import detfill, ref_spade_cpu as R
     m = model.modules_on_one_gpu
@@ -120,12 +120,12 @@ def cpu_baseline_spade(opt, model, args):
     sem = R.preprocess_input(lab, ins, 35)
     img = detfill.images((1, 3, h, w), 6)
     cores = torch.get_num_threads()
-    R.spade_step(st, sem, img)
     t0 = time.perf_counter()
     R.spade_step(st, sem, img)
     dt = time.perf_counter() - t0
     return {'value': round(1 / dt, 4), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
-            'sample': f'oracle/ref_spade_cpu.spade_step, batch 1 @ {w}x{h}, 1 warm-up + 1 timed step, {cores} torch threads'}
+            'sample': f'oracle/ref_spade_cpu.spade_step, batch 1 @ {w}x{h}, ONE timed step (no warm-up: ~20-40 s of host work), '
+                      f'{cores} torch threads'}
 
 
 def cpu_baseline(opt, model, args):
@@ -167,6 +167,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-profile', action='store_true')
     ap.add_argument('--no-overlap', action='store_true')
+    ap.add_argument('--teacher-side-stream', type=int, default=0, help='c2: run the frozen teacher forward on a side stream (1 GPU)')
     ap.add_argument('--graph', type=int, default=1, help='1 (default): replay the step as one captured hipGraph on 1 GPU; 0: eager launches')
     args = ap.parse_args()
     spade = args.workload == 'spade'
@@ -188,6 +189,8 @@ def main():
     model, opt = (build_spade_model if spade else build_model)(args, local)
     if args.no_overlap:
         model.teacher_side_stream = False
+    elif args.teacher_side_stream and not spade:
+        model.teacher_side_stream = True
     if world > 1:
         if spade:
             model.enable_data_parallel(parallel.DataParallelReducer())
@@ -210,7 +213,7 @@ def main():
 
     step = eager_step
     graphed = None
-    if args.graph and world == 1:
+    if args.graph and world == 1 and not getattr(model, 'teacher_side_stream', False):
         from cat_amd.graph import GraphedStep
         graphed = GraphedStep(model, batches[0])
 
@@ -244,6 +247,9 @@ def main():
     if world > 1:
         torch.distributed.barrier()
 
+    student_fwd = None
+    if rank == 0 and not args.no_kernel_profile:
+        student_fwd = student_forward_rate(model, batches[0], spade)
     ips = args.batch * world * args.steps / dt
     if spade:
         metric = f'distill-step images/sec @{2 * args.size}x{args.size} bs={args.batch} (GauGAN SPADEDistiller)'
@@ -262,6 +268,7 @@ def main():
         'config': {'workload': workload, 'image': image, 'per_gpu_batch': args.batch, 'global_batch': args.batch * world,
                    'parallelism': f'dp{world}', 'student_n_macs': n_macs, 'launch': 'hipGraph replay' if graphed is not None else 'eager'},
         'roofline': roofline,
+        'student_forward': student_fwd,
     }
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
@@ -271,9 +278,61 @@ def main():
         torch.distributed.destroy_process_group()
 
 
+def student_forward_rate(model, batch, spade):
+    """BASELINE's second headline figure: the student generator's forward alone (train-mode norms, no grad), as TFLOP/s of true conv
+    FLOPs and as a fraction of the fp32 MFMA peak.  FLOPs come from the library's own per-launch accounting (cat_prof_*)."""
+    import ctypes as C
+    from cat_amd import _lib
+    lib = _lib.load()
+    model.set_input(batch)
+    if spade:
+        net, x = model.modules_on_one_gpu.netG_student, model.input_semantics
+    else:
+        net, x = model.netG_student, model.real_A
+    with torch.no_grad():
+        for _ in range(3):
+            net(x)
+        torch.cuda.synchronize()
+        lib.cat_prof_enable(1)
+        net(x)
+        torch.cuda.synchronize()
+        n = lib.cat_prof_collect()
+        lib.cat_prof_enable(0)
+        name = C.create_string_buffer(64)
+        cnt, ms, fl = C.c_int64(), C.c_double(), C.c_double()
+        gflop = 0.0
+        for i in range(n):
+            lib.cat_prof_family(i, name, 64, C.byref(cnt), C.byref(ms), C.byref(fl))
+            gflop += fl.value / 1e9
+        # ~330 launches of a few microseconds each: issued from Python the forward is host-bound, so it is timed as a captured
+        # hipGraph (what GraphedStep replays inside the step); the eager figure is reported next to it
+        reps = 10
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            net(x)
+        e1.record()
+        torch.cuda.synchronize()
+        ms_eager = e0.elapsed_time(e1) / reps
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            net(x)
+        graph.replay()
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            graph.replay()
+        e1.record()
+        torch.cuda.synchronize()
+    ms_fwd = e0.elapsed_time(e1) / reps
+    tf = gflop / ms_fwd
+    return {'ms': round(ms_fwd, 3), 'ms_eager_launches': round(ms_eager, 3), 'gflop': round(gflop, 2), 'tflops': round(tf, 2), 'frac_of_fp32_mfma_peak': round(tf / MFMA_F32_PEAK_TFLOPS, 4),
+            'batch': int(x.shape[0])}
+
+
 def pmc_traffic(family):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
-    (profiles/r01_d_pmc_hbm.json: FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled per the gfx950 note in
+    (profiles/r01_e_pmc_hbm.json: FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled per the gfx950 note in
     MI355X_MICROARCH.md §HBM).  PMC collection cannot run inside the timed process, hence the lookup; None if absent."""
     path = os.path.join(ROOT, 'profiles', 'r01_d_pmc_hbm.json')
     if not os.path.exists(path):
@@ -328,7 +387,7 @@ def kernel_roofline(model, step, args):
     d = conv[dom]
     achieved = d['gflop_per_step'] / d['ms_per_step'] if d['ms_per_step'] > 0 else 0.0   # GFLOP/ms == TFLOP/s
     return {'bound': 'mfma', 'kernel': dom, 'achieved': round(achieved, 3), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-            'frac': round(achieved / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': pmc_traffic(dom),
+            'frac': round(achieved / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': pmc_traffic(dom) if getattr(args, 'workload', 'c2') == 'c2' else None,
             'avg_launch_us': round(1e3 * d['ms_per_step'] / max(d['launches_per_step'], 1), 3),
             'all_conv': {'achieved': round(tot_gf / tot_ms, 3) if tot_ms else 0.0, 'ms_per_step': round(tot_ms, 3),
                          'gflop_per_step': round(tot_gf, 2)},

@@ -1,0 +1,29 @@
+#!/bin/bash
+# Run ON THE GPU BOX (through gpurun) from the repo root: the round's measured artefacts -> gpurun_out/round/
+#   bench lines (c2 default incl. roofline + cpu_baseline, spade), rocprofv3 kernel-trace stats of the same commands,
+#   PMC passes (FETCH_SIZE / WRITE_SIZE separately, kernel-trace only -- never combined with sys/hip traces).
+set -x
+export TMPDIR=/tmp
+OUT=$PWD/gpurun_out/round
+mkdir -p $OUT
+if [ -z "$SKIP_BENCH" ]; then
+python bench.py > $OUT/bench_c2.json 2> $OUT/bench_c2.err
+python bench.py --workload spade > $OUT/bench_spade.json 2> $OUT/bench_spade.err
+fi
+# per-kernel durations are compared with bench.py's SERIAL roofline pass: branch streams off, no in-process event profiling
+export CAT_BRANCH_STREAMS=0
+B="python $PWD/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-profile --graph 0"
+(cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/prof_c2 -o bench -- $B > $OUT/prof_c2.log 2>&1)
+(cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/prof_spade -o bench -- $B --workload spade > $OUT/prof_spade.log 2>&1)
+if [ -z "$SKIP_PMC" ]; then
+P="python $PWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-profile --graph 0"
+(cd /tmp && rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc/fetch -o f -- $P > $OUT/pmc_fetch.log 2>&1)
+(cd /tmp && rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc/write -o w -- $P > $OUT/pmc_write.log 2>&1)
+fi
+# summarise on the box; only the summaries travel back (gpurun returns <= 64 MiB)
+python tools/rocprof_summary.py $OUT/prof_c2/bench_results.db $OUT/kernel_stats_c2.txt 6 > /dev/null
+python tools/rocprof_summary.py $OUT/prof_spade/bench_results.db $OUT/kernel_stats_spade.txt 6 > /dev/null
+[ -d $OUT/pmc ] && python tools/pmc_summary.py $OUT/pmc $OUT/pmc_hbm.json
+rm -rf $OUT/prof_c2 $OUT/prof_spade $OUT/pmc
+du -sh $OUT
+tail -c 600 $OUT/bench_c2.json; tail -c 300 $OUT/bench_spade.err
