@@ -38,6 +38,8 @@ class InceptionDistiller(BaseInceptionDistiller):
     def __init__(self, opt):
         assert opt.isTrain
         super(InceptionDistiller, self).__init__(opt)
+        from ..loss import MSELoss
+        self.criterionMSE = MSELoss()
         self.best_fid = 1e9
         self.best_mIoU = -1e9
         self.fids, self.mIoUs = [], []
@@ -54,18 +56,22 @@ class InceptionDistiller(BaseInceptionDistiller):
     def calc_distill_loss(self):
         """sum_i -KA(Sact_i, Tact_i) (inception_distiller.py:106-157, 'ka' branch).  Returns the per-layer terms; the
         weighted total is a LossValue (no torch arithmetic on the hot path)."""
-        if self.opt.distill_G_loss_type != 'ka':
-            raise NotImplementedError('distill_G_loss_type=%s: the accelerated path implements the KA loss the '
-                                      'distillation scripts use' % self.opt.distill_G_loss_type)
-        kas = []
+        kind = self.opt.distill_G_loss_type
+        if kind not in ('ka', 'mse'):
+            raise NotImplementedError(kind)
+        terms = []
         for i, netA in enumerate(self.netAs):
             assert isinstance(netA, nn.Conv2d)
             n = self.mapping_layers[i]
             key = n + str(self.device)
-            ka = KA(self.Sacts[key], self.Tacts[key])
-            setattr(self, 'loss_G_distill%d' % i, LossValue([(-1.0, ka)]))
-            kas.append(ka)
-        return kas
+            if kind == 'ka':
+                term = KA(self.Sacts[key], self.Tacts[key])
+                setattr(self, 'loss_G_distill%d' % i, LossValue([(-1.0, term)]))
+            else:       # 'mse' (:113-132): the student activation goes through the 1x1 adaptor netA first
+                term = self.criterionMSE(netA(self.Sacts[key]), self.Tacts[key])
+                setattr(self, 'loss_G_distill%d' % i, LossValue([(1.0, term)]))
+            terms.append(term)
+        return terms
 
     def backward_G(self, steps):
         opt = self.opt
@@ -84,11 +90,12 @@ class InceptionDistiller(BaseInceptionDistiller):
         terms, seeds = [gan, recon], [self.seed(opt.lambda_gan), self.seed(opt.lambda_recon)]
         if opt.lambda_distill > 0:
             kas = self.calc_distill_loss()
-            self.loss_G_distill = LossValue([(-opt.lambda_distill, k) for k in kas])
+            sign = -1.0 if opt.distill_G_loss_type == 'ka' else 1.0
+            self.loss_G_distill = LossValue([(sign * opt.lambda_distill, k) for k in kas])
             terms += kas
-            # DataParallel sums per-shard KA terms while every other term is a mean over the gathered batch: with
-            # gradient AVERAGING across ranks the KA seed therefore carries a factor world_size
-            seeds += [self.seed(-opt.lambda_distill * ws)] * len(kas)
+            # DataParallel sums the per-shard distillation terms (KA, or the per-device MSE) while every other term is a mean over
+            # the gathered batch: with gradient AVERAGING across ranks their seed therefore carries a factor world_size
+            seeds += [self.seed(sign * opt.lambda_distill * ws)] * len(kas)
         else:
             self.loss_G_distill = 0
         self.loss_G = self.loss_G_gan + self.loss_G_recon + self.loss_G_distill

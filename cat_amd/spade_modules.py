@@ -107,6 +107,7 @@ class SPADEDistillerModules(nn.Module):
             self.netAs.append(netA)
         self.criterionGAN = closs.GANLoss(opt.gan_mode)
         self.criterionFeat = closs.L1Loss()
+        self.criterionMSE = closs.MSELoss()
         self.criterionVGG = closs.VGGLoss(width_div=getattr(opt, 'vgg_width_div', 1))
         if len(self.gpu_ids) > 0:
             self.criterionVGG.to(torch.device('cuda', self.gpu_ids[0]))
@@ -155,13 +156,16 @@ class SPADEDistillerModules(nn.Module):
     # -- losses -------------------------------------------------------------------------------------------------------------
     def calc_distill_loss(self, Tacts, Sacts):
         """spade_distiller_modules.py:17-31."""
-        if self.opt.distill_G_loss_type != 'ka':
-            raise NotImplementedError('distill_G_loss_type=%s: the accelerated path implements the KA loss the distillation scripts '
-                                      'use' % self.opt.distill_G_loss_type)
+        kind = self.opt.distill_G_loss_type
+        if kind not in ('ka', 'mse'):
+            raise NotImplementedError(kind)
         losses = {}
         for i, netA in enumerate(self.netAs):
             layer = self.mapping_layers[i]
-            losses['G_distill%d' % i] = LossValue([(-1.0, closs.KA(Sacts[layer], Tacts[layer]))])
+            if kind == 'mse':
+                losses['G_distill%d' % i] = LossValue([(1.0, self.criterionMSE(netA(Sacts[layer]), Tacts[layer]))])
+            else:
+                losses['G_distill%d' % i] = LossValue([(-1.0, closs.KA(Sacts[layer], Tacts[layer]))])
         total = LossValue([(w * self.opt.lambda_distill, t) for lv in losses.values() for w, t in lv.terms])
         return total, losses
 

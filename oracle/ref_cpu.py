@@ -173,11 +173,13 @@ def adam_step(params, grads, state, lr, beta1, beta2=0.999, eps=1e-8):
 class DistillState:
     """Everything `InceptionDistiller.optimize_parameters` reads and writes (inception_distiller.py:179-188)."""
 
-    def __init__(self, teacher_sd, student_sd, d_sd, cfg):
+    def __init__(self, teacher_sd, student_sd, d_sd, cfg, netA_sds=None):
         self.cfg = dict(cfg)
         self.T = {k: v.clone() for k, v in teacher_sd.items()}
         self.S = {k: v.clone() for k, v in student_sd.items()}
         self.D = {k: v.clone() for k, v in d_sd.items()}
+        # the 1x1 adaptors netAs (base_inception_distiller.py:192-204): second param group of optimizer_G, used by 'mse' distillation
+        self.A = {} if netA_sds is None else {f'{i}.{k}': v.clone() for i, sd in enumerate(netA_sds) for k, v in sd.items()}
         self.adam_G, self.adam_D = {}, {}
         self.losses = OrderedDict()
 
@@ -242,8 +244,16 @@ def distill_step(st, real_A, real_B, n_shards=1):
         fake = Sfake_B
     loss_G_gan = gan_loss(gan_mode, netD(fake), True, for_discriminator=False) * cfg['lambda_gan']
     distill = []
-    for name in MAPPING_LAYERS:
-        li = sum(-ka(s[1][name], t[1][name]) for s, t in zip(s_out, t_out))
+    mse = cfg.get('distill_G_loss_type', 'ka') == 'mse'
+    if mse:
+        for v in st.A.values():
+            v.requires_grad_(True)
+            v.grad = None
+    for i, name in enumerate(MAPPING_LAYERS):
+        if mse:     # inception_distiller.py:113-132: per-device MSE(netA(Sact), Tact), summed over devices
+            li = sum(F.mse_loss(F.conv2d(s[1][name], st.A[f'{i}.weight'], st.A[f'{i}.bias']), t[1][name]) for s, t in zip(s_out, t_out))
+        else:
+            li = sum(-ka(s[1][name], t[1][name]) for s, t in zip(s_out, t_out))
         distill.append(li)
     loss_G_distill = sum(distill) * cfg['lambda_distill']
     loss_G = loss_G_gan + loss_G_recon + loss_G_distill
@@ -252,6 +262,11 @@ def distill_step(st, real_A, real_B, n_shards=1):
     adam_step(pS, {k: v.grad for k, v in pS.items()}, st.adam_G, cfg['lr'], cfg['beta1'])
     for v in pS.values():
         v.requires_grad_(False)
+    if mse:
+        pA = {'A.' + k: v for k, v in st.A.items()}
+        adam_step(pA, {k: v.grad for k, v in pA.items()}, st.adam_G, cfg['lr'], cfg['beta1'])
+        for v in st.A.values():
+            v.requires_grad_(False)
 
     st.losses = OrderedDict(G_gan=float(loss_G_gan), G_distill=float(loss_G_distill), G_recon=float(loss_G_recon),
                             D_fake=float(loss_D_fake), D_real=float(loss_D_real))

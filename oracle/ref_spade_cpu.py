@@ -272,8 +272,10 @@ def divide_pred(pred):
 class SpadeState:
     """What SPADEDistiller.optimize_parameters reads and writes."""
 
-    def __init__(self, teacher_sd, student_sd, d_sd, vgg_sd, cfg):
+    def __init__(self, teacher_sd, student_sd, d_sd, vgg_sd, cfg, netA_sds=None):
         self.cfg = dict(cfg)
+        # 1x1 adaptors netAs (base_spade_distiller_modules.py:75-87), trained only by distill_G_loss_type='mse'
+        self.A = {} if netA_sds is None else {f'{i}.{k}': v.clone() for i, sd in enumerate(netA_sds) for k, v in sd.items()}
         self.T = {k: v.clone() for k, v in teacher_sd.items()}
         self.S = {k: v.clone() for k, v in student_sd.items()}
         self.D = {k: v.clone() for k, v in d_sd.items()}
@@ -340,8 +342,17 @@ def spade_step(st, sem, real_B, n_shards=1):
         Tfake_B, Tacts = inception_spade_generator(st.T, sem, gcfg, training=False, mapping_layers=MAPPING_LAYERS)
     Sfake_B, Sacts = inception_spade_generator(st.S, sem, gcfg, training=True, synced=synced, mapping_layers=MAPPING_LAYERS)
     distill = []
-    for name in MAPPING_LAYERS:
-        distill.append(_shard_mean(lambda s, t: -ka(s, t), n_shards, Sacts[name], Tacts[name]))
+    mse = cfg.get('distill_G_loss_type', 'ka') == 'mse'
+    pA = OrderedDict(('A.' + k, v) for k, v in st.A.items())
+    for v in pA.values():
+        v.requires_grad_(mse)
+        v.grad = None
+    for i, name in enumerate(MAPPING_LAYERS):
+        if mse:     # spade_distiller_modules.py:23-25: F.mse_loss(netA(Sact), Tact)
+            fn = lambda s, t: F.mse_loss(F.conv2d(s, st.A[f'{i}.weight'], st.A[f'{i}.bias']), t)
+        else:
+            fn = lambda s, t: -ka(s, t)
+        distill.append(_shard_mean(fn, n_shards, Sacts[name], Tacts[name]))
     loss_G_distill = sum(distill) * cfg['lambda_distill']
     fakes, reals = discriminate(Sfake_B)
     loss_G_gan = sum(gan_loss('hinge', pf, True, for_discriminator=False) for pf in fakes) / n_shards * cfg['lambda_gan']
@@ -357,6 +368,10 @@ def spade_step(st, sem, real_B, n_shards=1):
     loss_G = loss_G_gan.reshape(()) + loss_G_distill + loss_G_feat + loss_G_vgg
     loss_G.backward()
     adam_step(pS, {k: v.grad for k, v in pS.items()}, st.adam_G, g_lr, b1, b2)
+    if mse:
+        adam_step(pA, {k: v.grad for k, v in pA.items()}, st.adam_G, g_lr, b1, b2)
+        for v in pA.values():
+            v.requires_grad_(False)
     st.grads_S = {k: v.grad.clone() for k, v in pS.items() if v.grad is not None}
     for v in pS.values():
         v.requires_grad_(False)

@@ -57,6 +57,16 @@ def disc_sd(opt, d_in):
     return detfill.fill_state_dict(D.state_dict(), SEED_D)
 
 
+def netA_sds(student_sd, teacher_ngf=64):
+    """state_dicts of the four 1x1 adaptors netAs (Conv2d(student trunk -> 4 * teacher_ngf)) as tools/make_golden.py fills them."""
+    trunk = student_sd['down_sampling.7.weight'].shape[0]
+    out = []
+    for i in range(4):
+        shapes = {'weight': torch.zeros(4 * teacher_ngf, trunk, 1, 1), 'bias': torch.zeros(4 * teacher_ngf)}
+        out.append(detfill.fill_state_dict(shapes, SEED_A + i))
+    return out
+
+
 def sub(t, cmax=8, step=8):
     return t.detach().cpu()[:, :cmax, ::step, ::step].contiguous().numpy()
 
@@ -90,6 +100,11 @@ def build_distiller(opt, student_shapes, d_in=None):
         d_in = 6 if opt.dataset_mode == 'aligned' else 3
     model.netD.load_state_dict(disc_sd(opt, d_in))
     model.netD.train()
+    trunk = student.state_dict()['down_sampling.7.weight'].shape[0]
+    from cat_amd import nn as cnn
+    model.netAs = [cnn.Conv2d(trunk, a.out_channels, 1).to(model.device) for a in model.netAs]      # shrink_model rebuilds them likewise
+    for a, sd in zip(model.netAs, netA_sds(student.state_dict())):
+        a.load_state_dict(sd)
     gp = [a.parameters() for a in model.netAs]
     model.optimizer_G = FusedAdam([{'params': model.netG_student.parameters()}, {'params': itertools.chain(*gp)}], lr=opt.lr,
                                   betas=(opt.beta1, 0.999))

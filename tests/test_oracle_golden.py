@@ -68,7 +68,7 @@ def test_forward(tag, norm, track, d_in, size):
     assert H.rel_err(yd.numpy(), g['disc_out']) < TOL
 
 
-@pytest.mark.parametrize('tag', ['in', 'bn'])
+@pytest.mark.parametrize('tag', ['in', 'bn', 'mse'])
 def test_two_distill_steps(tag):
     g = H.load(f'step_{tag}.npz')
     meta = json.loads(str(g['meta']))
@@ -76,9 +76,10 @@ def test_two_distill_steps(tag):
     d_in = 6 if meta['dataset_mode'] == 'aligned' else 3
     ncfg = H.cfg_for(meta['norm'])
     cfg = dict(T=ncfg, S=ncfg, D=ncfg, dataset_mode=meta['dataset_mode'], gan_mode=meta['gan_mode'], lambda_recon=meta['lambda_recon'],
-               lambda_distill=meta['lambda_distill'], lambda_gan=meta['lambda_gan'], lr=meta['lr'], beta1=meta['beta1'])
+               lambda_distill=meta['lambda_distill'], lambda_gan=meta['lambda_gan'], lr=meta['lr'], beta1=meta['beta1'],
+               distill_G_loss_type=meta.get('distill', 'ka'))
     S = detfill.fill_state_dict(H.sd_from_shapes(g['student_shapes']), H.SEED_S)
-    st = ref_cpu.DistillState(H.teacher_sd(opt), S, H.disc_sd(opt, d_in), cfg)
+    st = ref_cpu.DistillState(H.teacher_sd(opt), S, H.disc_sd(opt, d_in), cfg, H.netA_sds(S))
     for step in range(2):
         A = detfill.images((meta['nbatch'], 3, meta['size'], meta['size']), H.SEED_X + 10 + step)
         B = detfill.images((meta['nbatch'], 3, meta['size'], meta['size']), H.SEED_X + 20 + step)
@@ -91,9 +92,9 @@ def test_two_distill_steps(tag):
         # +-lr * sign(grad): round-off sized gradient differences can flip a sign, so the bound is looser
         assert H.rel_err(H.sub(st.Sfake_B, 3, 4), g[f'Sfake{step}']) < (2e-5 if step == 0 else 1e-3)
         for key in g.files:
-            if key.startswith(f'S{step}:') or key.startswith(f'D{step}:'):
+            if key.startswith(f'S{step}:') or key.startswith(f'D{step}:') or key.startswith(f'A{step}:'):
                 name = key.split(':', 1)[1]
-                sd = st.S if key[0] == 'S' else st.D
+                sd = {'S': st.S, 'D': st.D, 'A': st.A}[key[0]]
                 got = sd[name].detach().reshape(-1)[:len(g[key])].numpy()
                 # Adam's first steps move every weight by ~lr regardless of gradient scale: compare the UPDATE too
                 diff = np.abs(got - g[key])

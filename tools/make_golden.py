@@ -84,9 +84,9 @@ def gamma_dump(T):
     return g
 
 
-def run_config(tag, norm, track, target, dataset_mode, gan_mode, ndf, lam_recon, lam_distill, size, nbatch):
+def run_config(tag, norm, track, target, dataset_mode, gan_mode, ndf, lam_recon, lam_distill, size, nbatch, distill='ka', keep=('shrink', 'forward', 'step')):
     opt = ref_import.make_opt(norm=norm, track=track, target_flops=target, dataset_mode=dataset_mode, gan_mode=gan_mode, ndf=ndf,
-                              lambda_recon=lam_recon, lambda_distill=lam_distill)
+                              lambda_recon=lam_recon, lambda_distill=lam_distill, distill_G_loss_type=distill)
     T = teacher(opt)
     d_in = 6 if dataset_mode == 'aligned' else 3
     D = networks.define_D(d_in, ndf, 'n_layers', 3, norm, 'normal', 0.02, [], opt=opt)
@@ -127,7 +127,8 @@ def run_config(tag, norm, track, target, dataset_mode, gan_mode, ndf, lam_recon,
               'up_sampling.3.weight', 'up_sampling.7.weight']:
         if k in ssd:
             sh['copied:' + k] = ssd[k].numpy().copy()
-    np.savez_compressed(os.path.join(OUT, f'shrink_{tag}.npz'), **sh)
+    if 'shrink' in keep:
+        np.savez_compressed(os.path.join(OUT, f'shrink_{tag}.npz'), **sh)
     print(tag, 'shrink: thr', thr, 'student macs', s_macs[0], 'down', cfg['down'], 'up', cfg['up'], 'block0', cfg['blocks'][0])
 
     # ---- student forward (trainer.py:106-107 re-initialises the pruned student; here: deterministic fill) --------
@@ -158,7 +159,8 @@ def run_config(tag, norm, track, target, dataset_mode, gan_mode, ndf, lam_recon,
     with torch.no_grad():
         fw['disc_out'] = D(xd).numpy()
     D.load_state_dict(d_before)
-    np.savez_compressed(os.path.join(OUT, f'forward_{tag}.npz'), **fw)
+    if 'forward' in keep:
+        np.savez_compressed(os.path.join(OUT, f'forward_{tag}.npz'), **fw)
 
     # ---- two full optimize_parameters steps (inception_distiller.py:179-188) ----------------------------------
     st = {}
@@ -185,9 +187,12 @@ def run_config(tag, norm, track, target, dataset_mode, gan_mode, ndf, lam_recon,
         for k in ssd:
             if k in ('down_sampling.2.running_mean', 'down_sampling.2.running_var', 'features.0.pw_bn.running_var'):
                 st[f'S{step}:{k}'] = ssd[k].reshape(-1)[:16].numpy().copy()
+        for i, a in enumerate(m.netAs):        # the 1x1 adaptors only train with distill_G_loss_type='mse'
+            st[f'A{step}:{i}.weight'] = a.weight.detach().reshape(-1)[:64].numpy().copy()
+            st[f'A{step}:{i}.bias'] = a.bias.detach().reshape(-1)[:64].numpy().copy()
     st['meta'] = json.dumps(dict(norm=norm, track=track, dataset_mode=dataset_mode, gan_mode=gan_mode, ndf=ndf, lambda_recon=lam_recon,
                                  lambda_distill=lam_distill, lambda_gan=1.0, size=size, nbatch=nbatch, lr=opt.lr, beta1=opt.beta1,
-                                 target=target))
+                                 target=target, distill=distill))
     st['student_shapes'] = shapes_json(S.state_dict())
     np.savez_compressed(os.path.join(OUT, f'step_{tag}.npz'), **st)
     print(tag, 'step losses', {k: float(v) for k, v in st.items() if k.startswith('loss1')})
@@ -227,6 +232,10 @@ def small_ops():
 
 
 if __name__ == '__main__':
+    if os.environ.get('GOLDEN_ONLY') == 'mse':
+        # distill_G_loss_type='mse' (the flag's default, inception_distiller.py:113-132): MSE(netA(Sact), Tact) through the 1x1 adaptors
+        run_config('mse', 'instance', False, 2.6e9, 'unaligned', 'lsgan', 64, 5.0, 1.0, 64, 2, distill='mse', keep=('step',))
+        sys.exit(0)
     small_ops()
     # C3-like: CycleGAN student (InstanceNorm affine, lsgan, unaligned, ndf 64, lambda_recon 5), SURVEY §8d
     run_config('in', 'instance', False, 2.6e9, 'unaligned', 'lsgan', 64, 5.0, 1.0, 64, 2)
