@@ -241,15 +241,16 @@ def main():
     assert all(v == v for v in losses.values()), 'NaN loss'
     assert ops.STATS['conform_copies'] == 0
 
-    roofline = None
-    if not args.no_kernel_profile and rank == 0:
+    # the measurement passes run the step / the student forward again: with N > 1 ranks those contain collectives (gradient buckets,
+    # SynchronizedBatchNorm statistics), so EVERY rank executes them; rank 0 reports
+    roofline = student_fwd = None
+    if not args.no_kernel_profile and (rank == 0 or world > 1):
         roofline = kernel_roofline(model, eager_step, args)
+        if world > 1 and hasattr(model, 'finish_pending'):
+            model.finish_pending()
+        student_fwd = student_forward_rate(model, batches[0], spade, graph=world == 1)
     if world > 1:
         torch.distributed.barrier()
-
-    student_fwd = None
-    if rank == 0 and not args.no_kernel_profile:
-        student_fwd = student_forward_rate(model, batches[0], spade)
     ips = args.batch * world * args.steps / dt
     if spade:
         metric = f'distill-step images/sec @{2 * args.size}x{args.size} bs={args.batch} (GauGAN SPADEDistiller)'
@@ -278,7 +279,7 @@ def main():
         torch.distributed.destroy_process_group()
 
 
-def student_forward_rate(model, batch, spade):
+def student_forward_rate(model, batch, spade, graph=True):
     """BASELINE's second headline figure: the student generator's forward alone (train-mode norms, no grad), as TFLOP/s of true conv
     FLOPs and as a fraction of the fp32 MFMA peak.  FLOPs come from the library's own per-launch accounting (cat_prof_*)."""
     import ctypes as C
@@ -314,16 +315,17 @@ def student_forward_rate(model, batch, spade):
         e1.record()
         torch.cuda.synchronize()
         ms_eager = e0.elapsed_time(e1) / reps
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            net(x)
-        graph.replay()
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(reps):
-            graph.replay()
-        e1.record()
-        torch.cuda.synchronize()
+        if graph:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                net(x)
+            g.replay()
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(reps):
+                g.replay()
+            e1.record()
+            torch.cuda.synchronize()
     ms_fwd = e0.elapsed_time(e1) / reps
     tf = gflop / ms_fwd
     return {'ms': round(ms_fwd, 3), 'ms_eager_launches': round(ms_eager, 3), 'gflop': round(gflop, 2), 'tflops': round(tf, 2), 'frac_of_fp32_mfma_peak': round(tf / MFMA_F32_PEAK_TFLOPS, 4),

@@ -29,7 +29,9 @@ def init_distributed(backend=None):
     rank = int(os.environ['RANK'])
     local = int(os.environ.get('LOCAL_RANK', rank))
     if backend is None:
-        backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        backend = os.environ.get('CAT_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
+    if 'CAT_FORCE_DEVICE' in os.environ:      # test hook: several ranks on ONE GPU (gloo transport; RCCL needs one device per rank)
+        local = int(os.environ['CAT_FORCE_DEVICE'])
     if backend == 'nccl':
         torch.cuda.set_device(local)
     if not dist.is_initialized():
