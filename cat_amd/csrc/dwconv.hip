@@ -12,6 +12,9 @@ constexpr int MAXW = 16384;  // taps * cs floats of LDS filter (dynamic LDS, <= 
 struct DwArgs {
   const float* x; const float* w; const float* bias; float* y;
   int N, H, W, C, xcs, Ho, Wo, ycs, kh, kw, pad, reflect;
+  int cq;        // fwd: channel quads processed per pixel (the tensor, or a channel SLICE of a wider buffer: x / y point at its first channel)
+  int act;       // fwd: fused epilogue activation
+  float slope;
 };
 
 __device__ __forceinline__ void load_filter(float* sw, const float* w, int C, int cs, int taps) {
@@ -24,8 +27,8 @@ __device__ __forceinline__ void load_filter(float* sw, const float* w, int C, in
 
 __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs p) {
   extern __shared__ __attribute__((aligned(16))) float sw[];
-  const int taps = p.kh * p.kw, nq = p.ycs / 4;
-  load_filter(sw, p.w, p.C, p.ycs, taps);
+  const int taps = p.kh * p.kw, nq = p.cq, fcs = p.cq * 4;
+  load_filter(sw, p.w, p.C, fcs, taps);
   const int64_t total = (int64_t)p.N * p.Ho * p.Wo * nq;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int cq = (int)(i % nq);
@@ -50,11 +53,15 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs p) {
         if (p.reflect) ix = cat::reflect_idx(ix, p.W);
         else if ((unsigned)ix >= (unsigned)p.W) continue;
         const f4 xv = *reinterpret_cast<const f4*>(xn + ((int64_t)iy * p.W + ix) * p.xcs);
-        const f4 wv = *reinterpret_cast<const f4*>(sw + (ky * p.kw + kx) * p.ycs + c);
+        const f4 wv = *reinterpret_cast<const f4*>(sw + (ky * p.kw + kx) * fcs + c);
         acc += xv * wv;
       }
     }
-    *reinterpret_cast<f4*>(p.y + i * 4) = acc;
+    if (p.act != CAT_ACT_NONE) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] = c + e < p.C ? cat::apply_act(acc[e], p.act, p.slope) : 0.f;
+    }
+    *reinterpret_cast<f4*>(p.y + (i / nq) * p.ycs + c) = acc;
   }
 }
 
@@ -188,8 +195,14 @@ int cat_dwconv2d_fwd(const cat_conv_t* g, const float* x, const float* w, const 
   if (int e = dw_check(g)) return e;
   DwArgs a = dw_args(g);
   a.x = x; a.w = w; a.bias = bias; a.y = y;
-  cat::ProfScope prof("dwconv_fwd", 2.0 * g->N * g->Ho * g->Wo * g->Cin * g->kh * g->kw, 2 * 4.0 * (double)g->N * g->Ho * g->Wo * g->ycs, stream);
-  dw_fwd_kernel<<<ew_grid((int64_t)g->N * g->Ho * g->Wo * (g->ycs / 4)), 256, (size_t)g->kh * g->kw * g->ycs * sizeof(float), (hipStream_t)stream>>>(a);
+  // a channel SLICE of wider buffers: ycw (0 = whole tensor) gives the channels-with-padding this call owns; x / y point at its first one
+  const int own = g->ycw > 0 ? g->ycw : g->ycs;
+  CAT_REQUIRE(own % 4 == 0 && own >= g->Cin && own <= g->ycs && own <= g->xcs, "dwconv: bad channel slice (ycw=%d)", g->ycw);
+  a.cq = own / 4;
+  a.act = g->act;
+  a.slope = g->slope;
+  cat::ProfScope prof("dwconv_fwd", 2.0 * g->N * g->Ho * g->Wo * g->Cin * g->kh * g->kw, 2 * 4.0 * (double)g->N * g->Ho * g->Wo * own, stream);
+  dw_fwd_kernel<<<ew_grid((int64_t)g->N * g->Ho * g->Wo * a.cq), 256, (size_t)g->kh * g->kw * own * sizeof(float), (hipStream_t)stream>>>(a);
   return cat::check_launch("dwconv2d_fwd");
 }
 

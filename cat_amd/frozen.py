@@ -1,0 +1,154 @@
+"""Frozen-teacher fast path for InvertedResidualChannels (reference inception_modules.py:124-180, 230-236).
+
+In the distillation step the teacher runs in eval mode under no_grad (base_inception_distiller.py:168, inception_distiller.py:
+100-103).  With BatchNorm (running statistics) every norm of a block is a per-channel affine map, so the block
+
+    x + pw_bn( sum_k res_k(x) + sum_k dw_k(x) )
+
+collapses algebraically -- same values, different evaluation order -- into
+
+    A   one 1x1 conv  x -> [h_res1 | g_dw1 | g_dw3 | g_dw5]   (the four 256->42 convs + BN + ReLU as ONE GEMM with N = 176)
+    dw  three depthwise convs (+ BN + ReLU in the epilogue) reading / writing channel SLICES of the concatenated buffers
+    F   one 1x1 conv  [h_res1 | h_dw1 | h_dw3 | h_dw5] -> C  (the four 42->256 convs as ONE GEMM with K = 176; pw_bn's scale folded
+        into its weights, every bias of the block and pw_bn's shift folded into its bias)
+    k>1 res branches keep their two convs (first + BN + ReLU folded; second with pw_bn's scale folded in)
+    out = add_n(x, F, k3, k5)
+
+instead of 12 convs + 3 activations + add_n(6) + affine + add_n(2): the 42->256 1x1 layers were epilogue-bound (K = 44: 27 TFLOP/s),
+and 10 of 18 full-size tensor passes disappear.  One-time weight folding is cached per block (invalidated when a tensor changes).
+InstanceNorm teachers (CycleGAN configs) cannot be folded and take the general path."""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from . import nn as cnn
+from . import ops
+
+
+def _affine(bn):
+    scale = torch.rsqrt(bn.running_var + bn.eps)
+    if bn.weight is not None:
+        scale = scale * bn.weight
+    shift = -bn.running_mean * scale
+    if bn.bias is not None:
+        shift = shift + bn.bias
+    return scale, shift
+
+
+def _foldable(bn):
+    return isinstance(bn, cnn.BatchNorm2d) and bn.track_running_stats and not bn.training
+
+
+def applicable(block, x):
+    if torch.is_grad_enabled() or block.training or not x.is_cuda or len(block.res_ops) + len(block.dw_ops) == 0:
+        return False
+    if getattr(block, '_cat_frozen_off', False):
+        return False
+    norms = [op[1][1] for op in block.res_ops] + [op[0][1] for op in block.dw_ops] + [op[2][1] for op in block.dw_ops] + [block.pw_bn]
+    if not all(_foldable(n) for n in norms):
+        return False
+    return block.dropout_rate == 0 and len(block.dw_ops) + sum(1 for op in block.res_ops if op[1][0].kernel_size[0] == 1) >= 2
+
+
+def _tensors(block):
+    out = []
+    for m in block.modules():
+        for t in list(m._parameters.values()) + list(m._buffers.values()):
+            if t is not None:
+                out.append(t)
+    return out
+
+
+def _plan(block):
+    key = tuple((t.data_ptr(), t._version) for t in _tensors(block))
+    cached = getattr(block, '_cat_frozen', None)
+    if cached is not None and cached['key'] == key:
+        return cached
+    dev = block.pw_bn.running_mean.device
+    cin = block.input_dim
+    s_pw, t_pw = _affine(block.pw_bn)
+    pad_mode = L.PAD_REFLECT if block.padding_type == 'reflect' else L.PAD_ZERO
+    slots, wide = [], []          # slots: branches whose LAST conv is 1x1 (res k=1, every dw branch); wide: res branches with k > 1
+    for op in block.res_ops:
+        (slots if op[1][0].kernel_size[0] == 1 else wide).append(('res', op))
+    for op in block.dw_ops:
+        slots.append(('dw', op))
+    offs, off = [], 0
+    for kind, op in slots:
+        m = (op[1][0] if kind == 'res' else op[0][0]).out_channels
+        offs.append((off, m, ops.cs_for(m)))
+        off += ops.cs_for(m)
+    hc = off
+    w_a = ops.padded_weight_like((hc, cin, 1, 1), dev)
+    b_a = torch.zeros(hc, device=dev)
+    w_f = ops.padded_weight_like((cin, hc, 1, 1), dev)
+    b_f = t_pw.clone()
+    dws = []
+    act_mod = None
+    for (kind, op), (o, m, sz) in zip(slots, offs):
+        first = op[1] if kind == 'res' else op[0]             # ConvBNReLU: conv, norm, act
+        conv, bn, act_mod = first[0], first[1], first[2]
+        s1, t1 = _affine(bn)
+        w_a[o:o + m].copy_(conv.weight.detach() * s1.view(-1, 1, 1, 1))
+        b_a[o:o + m] = (conv.bias.detach() * s1 if conv.bias is not None else 0) + t1
+        last = op[4]
+        w_f[:, o:o + m].copy_(last.weight.detach() * s_pw.view(-1, 1, 1, 1))
+        if last.bias is not None:
+            b_f += last.bias.detach() * s_pw
+        if kind == 'dw':
+            dconv, dbn = op[2][0], op[2][1]
+            s2, t2 = _affine(dbn)
+            k = dconv.kernel_size[0]
+            dws.append(dict(off=o, m=m, sz=sz, k=k, pad=(k - 1) // 2,
+                            w=(dconv.weight.detach() * s2.view(-1, 1, 1, 1)).contiguous(),
+                            b=((dconv.bias.detach() * s2 if dconv.bias is not None else 0) + t2).contiguous()))
+    wides = []
+    for kind, op in wide:
+        last = op[4]
+        w2 = ops.padded_weight_like(tuple(last.weight.shape), dev)
+        w2.copy_(last.weight.detach() * s_pw.view(-1, 1, 1, 1))
+        if last.bias is not None:
+            b_f += last.bias.detach() * s_pw
+        wides.append(dict(op=op, w2=w2, k=last.kernel_size[0]))
+    act, slope = cnn._act_code(act_mod)
+    plan = dict(key=key, hc=hc, w_a=w_a, b_a=b_a.contiguous(), w_f=w_f, b_f=b_f.contiguous(), dws=dws, wides=wides, act=act, slope=slope,
+                pad_mode=pad_mode, copies=[(o, sz) for (kind, _), (o, m, sz) in zip(slots, offs) if kind == 'res'])
+    block._cat_frozen = plan
+    return plan
+
+
+def block_forward(block, x):
+    p = _plan(block)
+    x = ops.conform(x)
+    n, c, h, w = x.shape
+    hc = p['hc']
+    m_pix = n * h * w
+
+    def concat_chain(xi):
+        # A: every first-level 1x1 conv (+ folded BN + activation) as one GEMM
+        stc = ops._stream()
+        hbuf = ops.Conv2dFn.apply(xi, p['w_a'], p['b_a'], 1, 0, L.PAD_ZERO, p['act'], p['slope'])
+        h2 = ops.empty_act(n, hc, h, w, xi.device)
+        for o, sz in p['copies']:       # k = 1 res branch: its hidden activation already is the last conv's input
+            L.call('cat_slice_channels', ops._p(hbuf), hc, o, sz, C.c_void_p(h2.data_ptr() + 4 * o), hc, m_pix, stc)
+        for d in p['dws']:              # depthwise k x k (+ folded BN + activation) on a channel slice of the concatenated buffers
+            g = ops._conv_geom(n, h, w, d['m'], hc, h, w, d['m'], hc, d['k'], d['k'], 1, d['pad'], p['pad_mode'], p['act'], p['slope'], d['sz'])
+            L.call('cat_dwconv2d_fwd', C.byref(g), C.c_void_p(hbuf.data_ptr() + 4 * d['off']), ops._p(d['w']), ops._p(d['b']),
+                   C.c_void_p(h2.data_ptr() + 4 * d['off']), stc)
+        # F: every last 1x1 conv as one GEMM (pw_bn scale in the weights; all biases + pw_bn shift in the bias)
+        return ops.Conv2dFn.apply(h2, p['w_f'], p['b_f'], 1, 0, L.PAD_ZERO, L.ACT_NONE, 0.0)
+
+    def wide_chain(wd):
+        def run(xi):
+            op = wd['op']
+            hid = op[1](op[0](xi))      # pad -> conv k x k with folded BN + activation (FusedSequential's frozen path)
+            return ops.Conv2dFn.apply(hid, wd['w2'], None, 1, (wd['k'] - 1) // 2, p['pad_mode'], L.ACT_NONE, 0.0)
+        return run
+
+    fns = [concat_chain] + [wide_chain(wd) for wd in p['wides']]
+    if ops.branch_streams_enabled() and len(fns) > 1:
+        outs = ops.run_on_side_streams(fns, [x] * len(fns))
+    else:
+        outs = [fn(x) for fn in fns]
+    return ops.AddNFn.apply(x, *outs)

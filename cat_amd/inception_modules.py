@@ -8,6 +8,7 @@ import re
 import torch
 from torch import nn
 
+from . import frozen
 from . import nn as cnn
 from . import ops
 
@@ -146,6 +147,8 @@ class InvertedResidualChannels(nn.Module):
         nb = len(self.res_ops) + len(self.dw_ops)
         if nb == 0:
             return x
+        if frozen.applicable(self, x):      # eval + no_grad + BatchNorm: the frozen teacher's algebraically fused block
+            return frozen.block_forward(self, x)
         # one alias of x per consumer (branches + residual); their gradients are summed by one add_n kernel
         xs = ops.fanout(x, nb + 1)
         branch_ops = list(self.res_ops) + list(self.dw_ops)

@@ -70,7 +70,9 @@ int cat_conv2d_dgrad_ws(const cat_conv_t* g, const float* dy, const float* w, co
                         int dxcw, void* ws, cat_stream_t stream);
 
 /* Depthwise conv (groups == C), stride 1, weights [C][kh][kw]; replaces the groups=midp ConvBNReLU conv at
- * inception_modules.py:166-173.  dgrad for reflect padding again yields the padded-input gradient. */
+ * inception_modules.py:166-173.  dgrad for reflect padding again yields the padded-input gradient.
+ * fwd: g->act is applied in the epilogue; g->ycw > 0 makes the call operate on a channel SLICE of wider buffers (x and y
+ * point at the slice's first channel, xcs / ycs are the buffers' pixel strides, ycw = channels incl. padding the slice owns). */
 int cat_dwconv2d_fwd(const cat_conv_t* g, const float* x, const float* w, const float* bias, float* y,
                      cat_stream_t stream);
 int cat_dwconv2d_dgrad(const cat_conv_t* g, const float* dy, const float* w, float* dx, int dxcs,

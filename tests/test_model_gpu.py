@@ -139,3 +139,26 @@ def test_student_gradients_match_oracle(dev):
     # network-level gradient criterion (activation-kink flips move single tensors by O(1e-3) of the gradient scale): see check_grads
     import test_spade_gpu as TS
     TS.check_grads(model.netG_student.named_parameters(), st.grads_S)
+
+
+def test_frozen_teacher_block_fusion_equals_general_path(dev):
+    """cat_amd.frozen: the eval / no-grad BatchNorm teacher block evaluated as two concatenated 1x1 GEMMs + slice-wise depthwise convs
+    must equal the layer-by-layer path (and, through test_forward_matches_reference, the reference)."""
+    from cat_amd import frozen
+    opt = H.make_opt(norm='batch', track=True)
+    sd = H.teacher_sd(opt)
+    from cat_amd import networks
+    T = networks.define_G(3, 3, 64, 'inception_9blocks', 'batch', 0, 'normal', 0.02, [0], opt=opt)
+    T.load_state_dict(sd)
+    T.eval()
+    x = detfill.images((2, 3, 64, 64), 991).to(dev)
+    with torch.no_grad():
+        assert frozen.applicable(T.features[0], T.down_sampling(x))
+        y_fast = T(x)
+        for blk in T.features:
+            blk._cat_frozen_off = True
+        assert not frozen.applicable(T.features[0], T.down_sampling(x))
+        y_ref = T(x)
+    assert H.rel_err(y_fast.cpu().numpy(), y_ref.cpu().numpy()) < 5e-4      # 9 blocks deep, different (algebraically equal) evaluation order
+    T.train()
+    assert not frozen.applicable(T.features[0], x)
