@@ -372,3 +372,125 @@ def shrink_masks(gammas, thr, prune_cin_lb=1):
     return dict(down=[mask_lb(g) for g in gammas['down']],
                 blocks=[([g.abs() > thr for g in res], [g.abs() > thr for g in dw]) for res, dw in gammas['blocks']],
                 up=[mask_lb(g) for g in gammas['up']])
+
+
+# ---------------------------------------------------------------------------------------------- teacher-training steps
+class TrainState:
+    """Networks + Adam state of Pix2PixModel / CycleGANModel: dict name -> state_dict."""
+
+    def __init__(self, nets, cfg):
+        self.cfg = dict(cfg)
+        self.nets = {n: {k: v.clone() for k, v in sd.items()} for n, sd in nets.items()}
+        self.adam = {}
+        self.losses = OrderedDict()
+
+    @staticmethod
+    def params(sd):
+        return {k: v for k, v in sd.items() if not (k.endswith('running_mean') or k.endswith('running_var') or k.endswith('num_batches_tracked'))}
+
+    def grad_on(self, names, on):
+        for n in names:
+            for v in self.params(self.nets[n]).values():
+                v.requires_grad_(on)
+                v.grad = None
+
+    def adam_step(self, names, key):
+        for n in names:
+            p = {f'{n}.{k}': v for k, v in self.params(self.nets[n]).items()}
+            adam_step(p, {k: v.grad for k, v in p.items()}, self.adam.setdefault(key, {}), self.cfg['lr'], self.cfg['beta1'])
+
+
+def pix2pix_step(st, real_A, real_B):
+    """Pix2PixModel.optimize_parameters (models/pix2pix_model.py:156-207): forward, D step 0.5*(fake+real), G step GAN + lambda*recon."""
+    cfg = st.cfg
+    G, D = st.nets['G'], st.nets['D']
+    st.grad_on(['G'], True)
+    fake_B, _ = inception_generator(G, real_A, cfg['G'], training=True)
+    st.grad_on(['D'], True)
+    loss_D_fake = gan_loss(cfg['gan_mode'], nlayer_discriminator(D, torch.cat((real_A, fake_B), 1).detach(), cfg['D'], True), False, True)
+    loss_D_real = gan_loss(cfg['gan_mode'], nlayer_discriminator(D, torch.cat((real_A, real_B), 1).detach(), cfg['D'], True), True, True)
+    ((loss_D_fake + loss_D_real) * 0.5).backward()
+    st.adam_step(['D'], 'D')
+    st.grad_on(['D'], False)
+    loss_G_gan = gan_loss(cfg['gan_mode'], nlayer_discriminator(D, torch.cat((real_A, fake_B), 1), cfg['D'], True), True, False) * cfg['lambda_gan']
+    recon = F.l1_loss if cfg.get('recon_loss_type', 'l1') == 'l1' else F.mse_loss
+    loss_G_recon = recon(fake_B, real_B) * cfg['lambda_recon']
+    (loss_G_gan + loss_G_recon).backward()
+    st.grads_G = {k: v.grad.clone() for k, v in st.params(G).items() if v.grad is not None}
+    st.adam_step(['G'], 'G')
+    for v in st.params(G).values():
+        v.requires_grad_(False)
+    st.fake_B = fake_B.detach()
+    st.losses = OrderedDict(G_gan=float(loss_G_gan), G_recon=float(loss_G_recon), D_real=float(loss_D_real), D_fake=float(loss_D_fake))
+    return st.losses
+
+
+class ImagePoolRef:
+    """utils/image_pool.py:5-53 with an injected random source (same draw sequence as `random`)."""
+
+    def __init__(self, pool_size, rng):
+        self.pool_size, self.rng, self.num_imgs, self.images = pool_size, rng, 0, []
+
+    def query(self, images):
+        if self.pool_size == 0:
+            return images
+        out = []
+        for image in images:
+            image = image.detach().unsqueeze(0)
+            if self.num_imgs < self.pool_size:
+                self.num_imgs += 1
+                self.images.append(image)
+                out.append(image)
+            elif self.rng.uniform(0, 1) > 0.5:
+                i = self.rng.randint(0, self.pool_size - 1)
+                tmp = self.images[i].clone()
+                self.images[i] = image
+                out.append(tmp)
+            else:
+                out.append(image)
+        return torch.cat(out, 0)
+
+
+def cyclegan_step(st, real_A, real_B, pools):
+    """CycleGANModel.optimize_parameters (models/cycle_gan_model.py:226-303): forward (4 generator passes), G step (identity, GAN,
+    cycle), D_A / D_B steps on pooled fakes.  pools = (fake_A_pool, fake_B_pool)."""
+    cfg = st.cfg
+    gc, dc, mode = cfg['G'], cfg['D'], cfg['gan_mode']
+    GA, GB, DA, DB = (st.nets[n] for n in ('G_A', 'G_B', 'D_A', 'D_B'))
+    lam_idt, lam_A, lam_B = cfg['lambda_identity'], cfg['lambda_A'], cfg['lambda_B']
+    gen = lambda sd, x: inception_generator(sd, x, gc, training=True)[0]
+    dis = lambda sd, x: nlayer_discriminator(sd, x, dc, training=True)
+    st.grad_on(['G_A', 'G_B'], True)
+    st.grad_on(['D_A', 'D_B'], False)
+    fake_B = gen(GA, real_A)
+    rec_A = gen(GB, fake_B)
+    fake_A = gen(GB, real_B)
+    rec_B = gen(GA, fake_A)
+    if lam_idt > 0:
+        loss_idt_A = F.l1_loss(gen(GA, real_B), real_B) * lam_B * lam_idt
+        loss_idt_B = F.l1_loss(gen(GB, real_A), real_A) * lam_A * lam_idt
+    else:
+        loss_idt_A = loss_idt_B = torch.zeros(())
+    loss_G_A = gan_loss(mode, dis(DA, fake_B), True)
+    loss_G_B = gan_loss(mode, dis(DB, fake_A), True)
+    loss_cycle_A = F.l1_loss(rec_A, real_A) * lam_A
+    loss_cycle_B = F.l1_loss(rec_B, real_B) * lam_B
+    (loss_G_A + loss_G_B + loss_cycle_A + loss_cycle_B + loss_idt_A + loss_idt_B).backward()
+    st.adam_step(['G_A', 'G_B'], 'G')
+    st.grad_on(['G_A', 'G_B'], False)
+    st.grad_on(['D_A', 'D_B'], True)
+
+    def d_basic(sd, real, fake):
+        l_real = gan_loss(mode, dis(sd, real), True)
+        l_fake = gan_loss(mode, dis(sd, fake.detach()), False)
+        loss = (l_real + l_fake) * 0.5
+        loss.backward()
+        return loss
+    loss_D_A = d_basic(DA, real_B, pools[1].query(fake_B))
+    loss_D_B = d_basic(DB, real_A, pools[0].query(fake_A))
+    st.adam_step(['D_A', 'D_B'], 'D')
+    st.grad_on(['D_A', 'D_B'], False)
+    st.fake_A, st.fake_B = fake_A.detach(), fake_B.detach()
+    st.losses = OrderedDict(D_A=float(loss_D_A), G_A=float(loss_G_A), G_cycle_A=float(loss_cycle_A), G_idt_A=float(loss_idt_A),
+                            D_B=float(loss_D_B), G_B=float(loss_G_B), G_cycle_B=float(loss_cycle_B), G_idt_B=float(loss_idt_B))
+    return st.losses

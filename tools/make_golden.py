@@ -231,7 +231,83 @@ def small_ops():
     print('small ops done')
 
 
+def teacher_training_steps():
+    """Two optimize_parameters steps of Pix2PixModel and CycleGANModel (models/pix2pix_model.py:198-207, cycle_gan_model.py:292-303),
+    constructed without their dataset / FID members like the distillers (SURVEY §8c recipe step 5)."""
+    import random
+    from models.pix2pix_model import Pix2PixModel
+    from models.cycle_gan_model import CycleGANModel
+    from utils.image_pool import ImagePool
+    out = {}
+    size, n = 64, 2
+    # ---- pix2pix: BatchNorm (tracked), hinge, aligned -------------------------------------------------------------------------
+    opt = ref_import.make_opt(norm='batch', track=True, ndf=32, gan_mode='hinge', lambda_recon=10.0, ngf=16, netG='inception_9blocks',
+                              dropout_rate=0, direction='AtoB', lambda_comp_cost=0)
+    m = Pix2PixModel.__new__(Pix2PixModel)
+    m.opt, m.gpu_ids, m.isTrain, m.device = opt, [], True, torch.device('cpu')
+    m.netG = networks.define_G(3, 3, opt.ngf, 'inception_9blocks', opt.norm, 0, 'normal', 0.02, [], opt=opt)
+    m.netD = networks.define_D(6, opt.ndf, 'n_layers', 3, opt.norm, 'normal', 0.02, [], opt=opt)
+    m.netG.load_state_dict(detfill.fill_state_dict(m.netG.state_dict(), 301))
+    m.netD.load_state_dict(detfill.fill_state_dict(m.netD.state_dict(), 302))
+    m.criterionGAN, m.criterionRecon = GANLoss(opt.gan_mode), torch.nn.L1Loss()
+    m.optimizer_G = Adam(m.netG.parameters(), lr=opt.lr, betas=(opt.beta1, 0.999))
+    m.optimizer_D = Adam(m.netD.parameters(), lr=opt.lr, betas=(opt.beta1, 0.999))
+    out['p2p_G_shapes'], out['p2p_D_shapes'] = shapes_json(m.netG.state_dict()), shapes_json(m.netD.state_dict())
+    probes_G = ['down_sampling.1.weight', 'features.4.res_ops.2.1.0.weight', 'features.7.dw_ops.1.2.1.weight', 'up_sampling.7.weight']
+    probes_D = ['model.0.weight', 'model.5.weight', 'model.11.weight']
+    for step in range(2):
+        A, B = detfill.images((n, 3, size, size), 310 + step), detfill.images((n, 3, size, size), 320 + step)
+        m.set_input({'A': A, 'B': B, 'A_paths': [], 'B_paths': []})
+        m.optimize_parameters(step)
+        for k in ('G_gan', 'G_recon', 'D_real', 'D_fake'):
+            out[f'p2p_loss{step}:{k}'] = np.float64(getattr(m, 'loss_' + k).item())
+        out[f'p2p_fake{step}'] = sub(m.fake_B, 3, 4)
+        for k in probes_G:
+            out[f'p2p_G{step}:{k}'] = m.netG.state_dict()[k].reshape(-1)[:64].numpy().copy()
+        for k in probes_D:
+            out[f'p2p_D{step}:{k}'] = m.netD.state_dict()[k].reshape(-1)[:64].numpy().copy()
+        out[f'p2p_G{step}:down_sampling.2.running_var'] = m.netG.state_dict()['down_sampling.2.running_var'].numpy().copy()
+    out['p2p_meta'] = json.dumps(dict(norm='batch', track=True, ndf=32, ngf=16, gan_mode='hinge', lambda_recon=10.0, lambda_gan=1.0, lr=opt.lr,
+                                      beta1=opt.beta1, size=size, nbatch=n))
+    # ---- cycle_gan: InstanceNorm, lsgan, pool of 2 images (so the random swap path runs in step 2 and 3) ------------------------------
+    opt = ref_import.make_opt(norm='instance', track=False, ndf=16, gan_mode='lsgan', ngf=8, netG='inception_9blocks', dropout_rate=0,
+                              direction='AtoB', dataset_mode='unaligned', lambda_A=10.0, lambda_B=10.0, lambda_identity=0.5, pool_size=2)
+    c = CycleGANModel.__new__(CycleGANModel)
+    c.opt, c.gpu_ids, c.isTrain, c.device = opt, [], True, torch.device('cpu')
+    for i, name in enumerate(('G_A', 'G_B')):
+        net = networks.define_G(3, 3, opt.ngf, 'inception_9blocks', opt.norm, 0, 'normal', 0.02, [], opt=opt)
+        net.load_state_dict(detfill.fill_state_dict(net.state_dict(), 401 + i))
+        setattr(c, 'net' + name, net)
+    for i, name in enumerate(('D_A', 'D_B')):
+        net = networks.define_D(3, opt.ndf, 'n_layers', 3, opt.norm, 'normal', 0.02, [], opt=opt)
+        net.load_state_dict(detfill.fill_state_dict(net.state_dict(), 411 + i))
+        setattr(c, 'net' + name, net)
+    c.fake_A_pool, c.fake_B_pool = ImagePool(opt.pool_size), ImagePool(opt.pool_size)
+    c.criterionGAN, c.criterionCycle, c.criterionIdt = GANLoss(opt.gan_mode), torch.nn.L1Loss(), torch.nn.L1Loss()
+    c.optimizer_G = Adam(itertools.chain(c.netG_A.parameters(), c.netG_B.parameters()), lr=opt.lr, betas=(opt.beta1, 0.999))
+    c.optimizer_D = Adam(itertools.chain(c.netD_A.parameters(), c.netD_B.parameters()), lr=opt.lr, betas=(opt.beta1, 0.999))
+    out['cyc_G_shapes'], out['cyc_D_shapes'] = shapes_json(c.netG_A.state_dict()), shapes_json(c.netD_A.state_dict())
+    random.seed(1234)
+    names = ['D_A', 'G_A', 'G_cycle_A', 'G_idt_A', 'D_B', 'G_B', 'G_cycle_B', 'G_idt_B']
+    for step in range(3):
+        A, B = detfill.images((1, 3, size, size), 420 + step), detfill.images((1, 3, size, size), 430 + step)
+        c.set_input({'A': A, 'B': B})
+        c.optimize_parameters(step)
+        for k in names:
+            out[f'cyc_loss{step}:{k}'] = np.float64(float(getattr(c, 'loss_' + k)))
+        out[f'cyc_fakeB{step}'] = sub(c.fake_B, 3, 4)
+        for nm, key in (('G_A', 'features.3.res_ops.1.1.0.weight'), ('G_B', 'up_sampling.7.weight'), ('D_A', 'model.0.weight'), ('D_B', 'model.8.weight')):
+            out[f'cyc_{nm}{step}:{key}'] = getattr(c, 'net' + nm).state_dict()[key].reshape(-1)[:64].numpy().copy()
+    out['cyc_meta'] = json.dumps(dict(norm='instance', ndf=16, ngf=8, gan_mode='lsgan', lambda_A=10.0, lambda_B=10.0, lambda_identity=0.5,
+                                      pool_size=2, lr=opt.lr, beta1=opt.beta1, size=size, seed=1234))
+    np.savez_compressed(os.path.join(OUT, 'train_steps.npz'), **out)
+    print('train_steps.npz', {k: float(v) for k, v in out.items() if 'loss1' in k})
+
+
 if __name__ == '__main__':
+    if os.environ.get('GOLDEN_ONLY') == 'train':
+        teacher_training_steps()
+        sys.exit(0)
     if os.environ.get('GOLDEN_ONLY') == 'mse':
         # distill_G_loss_type='mse' (the flag's default, inception_distiller.py:113-132): MSE(netA(Sact), Tact) through the 1x1 adaptors
         run_config('mse', 'instance', False, 2.6e9, 'unaligned', 'lsgan', 64, 5.0, 1.0, 64, 2, distill='mse', keep=('step',))
