@@ -47,6 +47,20 @@ class InceptionDistiller(BaseInceptionDistiller):
         model_profiling(self.netG_teacher, h, w, channel=getattr(opt, 'data_channel', 3))
         model_profiling(self.netG_student, h, w, channel=getattr(opt, 'data_channel', 3))
 
+    def load_networks(self, verbose=True, teacher_only=False, restore_pretrain=True):
+        """inception_distiller.py:190-203: a wider pretrained generator seeds the student by top-k L1 channel selection
+        (cat_amd.weight_transfer, host-side, once) before the regular checkpoints are restored."""
+        opt = self.opt
+        if getattr(opt, 'restore_pretrained_G_path', None) is not None and restore_pretrain:
+            from .. import networks
+            from ..weight_transfer import load_pretrained_weight
+            pre = networks.define_G(opt.input_nc, opt.output_nc, opt.pretrained_ngf, opt.pretrained_netG, opt.norm, 0, opt.init_type,
+                                    opt.init_gain, [], opt=opt)
+            self._load(pre, opt.restore_pretrained_G_path, verbose)
+            load_pretrained_weight(opt.pretrained_netG, opt.student_netG, pre, self.netG_student, opt.pretrained_ngf, opt.student_ngf)
+            del pre
+        super(InceptionDistiller, self).load_networks(verbose, teacher_only=teacher_only, restore_pretrain=restore_pretrain)
+
     def forward(self, teacher_forward=True):
         if teacher_forward:
             with torch.no_grad():

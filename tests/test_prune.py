@@ -78,3 +78,29 @@ def test_shrink_spade_bit_exact(tag):
     assert [k for k, _ in s_shapes] == list(sd.keys())
     assert all(list(sd[k].shape) == shp for k, shp in s_shapes)
     assert model_profiling(S, opt.data_height, opt.data_width, channel=opt.data_channel)[0] == int(g[f'{tag}_n_macs'])
+
+
+def test_load_pretrained_weight_bit_exact():
+    """cat_amd.weight_transfer.load_pretrained_weight (ngf 32 -> 20) against the reference's run: the transfer is pure top-k index
+    selection + copy, so every student tensor must equal the reference's exactly (fingerprints of all 472 tensors, 5 in full)."""
+    import json
+    from cat_amd import networks
+    from cat_amd.weight_transfer import load_pretrained_weight
+    g = H.load('weight_transfer.npz')
+    opt = H.make_opt(norm='instance', track=False, gpu_ids=[])
+    A = networks.define_G(3, 3, 32, 'inception_9blocks', 'instance', 0, 'normal', 0.02, [], opt=opt)
+    B = networks.define_G(3, 3, 20, 'inception_9blocks', 'instance', 0, 'normal', 0.02, [], opt=opt)
+    assert [k for k, _ in json.loads(str(g['A_shapes']))] == list(A.state_dict().keys())
+    A.load_state_dict(detfill.fill_state_dict(A.state_dict(), 501))
+    B.load_state_dict(detfill.fill_state_dict(B.state_dict(), 502))
+    load_pretrained_weight('inception_9blocks', 'inception_9blocks', A, B, 32, 20)
+    sd = B.state_dict()
+    assert [k for k, _ in json.loads(str(g['B_shapes']))] == list(sd.keys())
+    for (k, v), ref in zip(sd.items(), g['B_fingerprints']):
+        d = v.double().reshape(-1)
+        w = torch.arange(1, d.numel() + 1, dtype=torch.float64)
+        got = np.array([float(d.sum()), float((d * w).sum()), float((d * d).sum())])
+        assert np.array_equal(got, ref), (k, got, ref)
+    for key in g.files:
+        if key.startswith('B:'):
+            np.testing.assert_array_equal(sd[key[2:]].numpy(), g[key])

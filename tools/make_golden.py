@@ -304,7 +304,34 @@ def teacher_training_steps():
     print('train_steps.npz', {k: float(v) for k, v in out.items() if 'loss1' in k})
 
 
+def weight_transfer_golden():
+    """load_pretrained_weight (utils/weight_transfer.py:240-266) ngf 32 -> ngf 20, inception_9blocks, seeded pretrained weights."""
+    from utils.weight_transfer import load_pretrained_weight
+    opt = ref_import.make_opt(norm='instance', track=False)
+    A = networks.define_G(3, 3, 32, 'inception_9blocks', 'instance', 0, 'normal', 0.02, [], opt=opt)
+    B = networks.define_G(3, 3, 20, 'inception_9blocks', 'instance', 0, 'normal', 0.02, [], opt=opt)
+    A.load_state_dict(detfill.fill_state_dict(A.state_dict(), 501))
+    B.load_state_dict(detfill.fill_state_dict(B.state_dict(), 502))
+    load_pretrained_weight('inception_9blocks', 'inception_9blocks', A, B, 32, 20)
+    out = {'A_shapes': shapes_json(A.state_dict()), 'B_shapes': shapes_json(B.state_dict())}
+    sd = B.state_dict()
+    # pure index selection (no arithmetic): exact fingerprints of every tensor pin it bit for bit without shipping 3 MB of weights
+    fp = []
+    for k, v in sd.items():
+        d = v.double().reshape(-1)
+        w = torch.arange(1, d.numel() + 1, dtype=torch.float64)
+        fp.append([float(d.sum()), float((d * w).sum()), float((d * d).sum())])
+    out['B_fingerprints'] = np.array(fp, dtype=np.float64)
+    for k in ('down_sampling.1.weight', 'features.2.res_ops.1.1.0.weight', 'features.5.dw_ops.2.2.0.weight', 'up_sampling.3.weight', 'up_sampling.7.weight'):
+        out['B:' + k] = sd[k].numpy().copy()
+    np.savez_compressed(os.path.join(OUT, 'weight_transfer.npz'), **out)
+    print('weight_transfer.npz', len(sd), 'tensors')
+
+
 if __name__ == '__main__':
+    if os.environ.get('GOLDEN_ONLY') == 'transfer':
+        weight_transfer_golden()
+        sys.exit(0)
     if os.environ.get('GOLDEN_ONLY') == 'train':
         teacher_training_steps()
         sys.exit(0)
