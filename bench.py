@@ -215,10 +215,15 @@ def main():
     graphed = None
     if args.graph and world == 1 and not getattr(model, 'teacher_side_stream', False):
         from cat_amd.graph import GraphedStep
-        graphed = GraphedStep(model, batches[0])
-
-        def step(i):
-            graphed(batches[i % nbuf])
+        try:
+            graphed = GraphedStep(model, batches[0])
+        except Exception as e:      # a failed capture must not cost the measurement: fall back to eager launches and say so
+            print(f'[bench] hipGraph capture failed ({type(e).__name__}: {e}); timing eager launches', file=sys.stderr, flush=True)
+            graphed = None
+            torch.cuda.synchronize()
+        if graphed is not None:
+            def step(i):
+                graphed(batches[i % nbuf])
 
     def barrier():
         if world > 1:
@@ -258,7 +263,7 @@ def main():
                     f'{args.target_flops:.2g} MACs + multiscale SN-PatchGAN ndf64, hinge + feat + VGG + KA, TTUR Adam x2')
         image, n_macs = f'{2 * args.size}x{args.size}', int(model.modules_on_one_gpu.netG_student.n_macs)
     else:
-        metric = 'distill-step images/sec @256x256 bs=16'
+        metric = f'distill-step images/sec @{args.size}x{args.size} bs={args.batch}'      # default: BASELINE.json's @256x256 bs=16
         workload = ('pix2pix InceptionDistiller.optimize_parameters (BASELINE configs[1]): teacher ngf64 frozen + student '
                     f'pruned to {args.target_flops:.2g} MACs + PatchGAN ndf128, hinge + L1 + KA, Adam x2')
         image, n_macs = f'{args.size}x{args.size}', int(model.netG_student.n_macs)

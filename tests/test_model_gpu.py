@@ -151,7 +151,8 @@ def test_frozen_teacher_block_fusion_equals_general_path(dev):
     T = networks.define_G(3, 3, 64, 'inception_9blocks', 'batch', 0, 'normal', 0.02, [0], opt=opt)
     T.load_state_dict(sd)
     T.eval()
-    x = detfill.images((2, 3, 64, 64), 991).to(dev)
+    from cat_amd import ops
+    x = ops.to_nhwc(detfill.images((2, 3, 64, 64), 991).to(dev))
     with torch.no_grad():
         assert frozen.applicable(T.features[0], T.down_sampling(x))
         y_fast = T(x)

@@ -283,6 +283,7 @@ def test_generator_forward_backward(which):
     sd = sds['S'] if train else sds['T']
     G = make_G(opt, opt.student_ngf if train else opt.teacher_ngf, sd, train)
     from cat_amd import ops
+    ops.STATS['conform_copies'] = 0
     gsem = ops.onehot_edges(lab.to(dev()), ins.to(dev()), opt.input_nc)
     r = detfill.normal((2, 3, int(g['h']), int(g['w'])), 77)
     if train:
@@ -315,6 +316,7 @@ def test_multiscale_discriminator_forward_backward():
     D = networks.define_D(opt.input_nc + 3, opt.ndf, 'multi_scale', 4, 'instance', 'xavier', 0.02, [0], opt=opt)
     D.load_state_dict(sds['D'])
     D.train()
+    ops.STATS['conform_copies'] = 0
     x = torch.cat([detfill.normal((4, opt.semantic_nc, 64, 96), 90).gt(0.5).float(), detfill.images((4, 3, 64, 96), 91)], 1)
     gx = nhwc(x).requires_grad_(True)
     out = D(gx)
@@ -369,6 +371,8 @@ def test_spade_distill_step():
     g, opt, lab, ins, img, sds, cfg = fixture()
     opt.isTrain, opt.distiller, opt.log_dir = True, 'spade', '/tmp/cat_amd_logs'
     model = build_spade_distiller(opt, sds)
+    from cat_amd import ops
+    ops.STATS['conform_copies'] = 0
     model.set_input({'label': lab.float(), 'instance': ins, 'image': img, 'path': []})
     np.testing.assert_array_equal(model.input_semantics[:, -1].cpu().numpy().astype(np.uint8), g['sem_edge'])
     model.optimize_parameters(0)

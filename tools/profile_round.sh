@@ -9,6 +9,8 @@ mkdir -p $OUT
 if [ -z "$SKIP_BENCH" ]; then
 python bench.py > $OUT/bench_c2.json 2> $OUT/bench_c2.err
 python bench.py --workload spade > $OUT/bench_spade.json 2> $OUT/bench_spade.err
+python bench.py --size 512 --batch 16 --steps 6 --warmup 2 --no-cpu-baseline > $OUT/bench_c2_512.json 2> $OUT/bench_c2_512.err
+python -c 'import __graft_entry__ as g; g.smoke()' > $OUT/smoke.log 2>&1
 fi
 # per-kernel durations are compared with bench.py's SERIAL roofline pass: branch streams off, no in-process event profiling
 export CAT_BRANCH_STREAMS=0
