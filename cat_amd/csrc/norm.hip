@@ -109,30 +109,27 @@ __global__ __launch_bounds__(256) void norm_fwd_finalize_kernel(const float* __r
                                                                 float* __restrict__ running_mean, float* __restrict__ running_var,
                                                                 float* __restrict__ scale, float* __restrict__ shift, int G, int Pg,
                                                                 int C, int cs, int nb, float eps, float momentum) {
-  // grid (cdiv(cs,64), G); 64 channels x 4 partial-lanes per block
-  __shared__ float red[2][256];
-  const int g = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), j = threadIdx.x >> 6;
-  float s0 = 0.f, s1 = 0.f;
-  if (c < C) {
-    for (int b = j; b < nb; b += 4) {
-      const float* src = part + ((int64_t)(g * nb + b) * 2) * cs + c;
-      s0 += src[0];
-      s1 += src[cs];
-    }
-  }
-  red[0][threadIdx.x] = s0;
-  red[1][threadIdx.x] = s1;
-  __syncthreads();
-  if (j != 0 || c >= cs) return;
+  // grid (cdiv(cs,4), G); one WAVE per channel: 64 lanes stride over the nb partial blocks, wave-shuffle reduce (the serial
+  // 64-channels x 4-lanes version cost 55 us at nb = 1024 -- more than the stats pass it finishes)
+  const int g = blockIdx.y, c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (c >= cs) return;
   const int idx = g * cs + c;
   if (c >= C) {
-    scale[idx] = 0.f;
-    shift[idx] = 0.f;
+    if (lane == 0) {
+      scale[idx] = 0.f;
+      shift[idx] = 0.f;
+    }
     return;
   }
-  const int l = threadIdx.x;
-  s0 = (red[0][l] + red[0][l + 64]) + (red[0][l + 128] + red[0][l + 192]);
-  s1 = (red[1][l] + red[1][l + 64]) + (red[1][l + 128] + red[1][l + 192]);
+  float s0 = 0.f, s1 = 0.f;
+  for (int b = lane; b < nb; b += 64) {
+    const float* src = part + ((int64_t)(g * nb + b) * 2) * cs + c;
+    s0 += src[0];
+    s1 += src[cs];
+  }
+  s0 = cat::wave_sum(s0);
+  s1 = cat::wave_sum(s1);
+  if (lane != 0) return;
   const float inv = 1.f / (float)Pg;
   const float d = s0 * inv;
   const float mean = x[(int64_t)g * Pg * cs + c] + d;
@@ -172,24 +169,20 @@ __global__ __launch_bounds__(256) void norm_bwd_finalize_kernel(const float* __r
                                                                 const float* __restrict__ rstd, float* __restrict__ c1,
                                                                 float* __restrict__ c2, float* __restrict__ scale, int Pg, int C, int cs,
                                                                 int nb) {
-  // grid (cdiv(cs,64), G); 64 channels x 4 partial-lanes per block: per-(group, channel) means of g and g*xhat
-  __shared__ float red[2][256];
-  const int g = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), j = threadIdx.x >> 6;
+  // grid (cdiv(cs,4), G); one wave per channel (see norm_fwd_finalize_kernel): per-(group, channel) means of g and g*xhat
+  const int g = blockIdx.y, c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (c >= cs) return;
   float s0 = 0.f, s1 = 0.f;
   if (c < C) {
-    for (int b = j; b < nb; b += 4) {
+    for (int b = lane; b < nb; b += 64) {
       const float* src = part + ((int64_t)(g * nb + b) * 2) * cs + c;
       s0 += src[0];
       s1 += src[cs];
     }
   }
-  red[0][threadIdx.x] = s0;
-  red[1][threadIdx.x] = s1;
-  __syncthreads();
-  if (j != 0 || c >= cs) return;
-  const int l = threadIdx.x;
-  s0 = (red[0][l] + red[0][l + 64]) + (red[0][l + 128] + red[0][l + 192]);
-  s1 = (red[1][l] + red[1][l + 64]) + (red[1][l + 128] + red[1][l + 192]);
+  s0 = cat::wave_sum(s0);
+  s1 = cat::wave_sum(s1);
+  if (lane != 0) return;
   const float inv = 1.f / (float)Pg;
   c1[g * cs + c] = s0 * inv;
   c2[g * cs + c] = s1 * inv;
@@ -289,7 +282,7 @@ int cat_norm_fwd(const cat_norm_t* g, const float* x, const float* gamma, const 
   hipStream_t s = (hipStream_t)stream;
   norm_stats_kernel<0><<<dim3(p.nb, p.G, p.nz), 256, 0, s>>>(x, nullptr, nullptr, nullptr, nullptr, nullptr, w + p.part_off, p.Pg,
                                                               g->C, g->cs, p.zq, p.ppl, p.nb, 0, 0.f);
-  norm_fwd_finalize_kernel<<<dim3(cdiv(g->cs, 64), p.G), 256, 0, s>>>(x, w + p.part_off, gamma, beta, save_mean, save_rstd,
+  norm_fwd_finalize_kernel<<<dim3(cdiv(g->cs, 4), p.G), 256, 0, s>>>(x, w + p.part_off, gamma, beta, save_mean, save_rstd,
                                                                    g->mode == CAT_NORM_BATCH ? running_mean : nullptr,
                                                                    g->mode == CAT_NORM_BATCH ? running_var : nullptr, w + p.scale_off,
                                                                    w + p.shift_off, p.G, p.Pg, g->C, g->cs, p.nb, g->eps, g->momentum);
@@ -309,7 +302,7 @@ int cat_norm_bwd(const cat_norm_t* g, const float* x, const float* dy, const flo
   hipStream_t s = (hipStream_t)stream;
   norm_stats_kernel<1><<<dim3(p.nb, p.G, p.nz), 256, 0, s>>>(x, dy, gamma, beta, save_mean, save_rstd, w + p.part_off, p.Pg, g->C, g->cs,
                                                               p.zq, p.ppl, p.nb, g->act, g->slope);
-  norm_bwd_finalize_kernel<<<dim3(cdiv(g->cs, 64), p.G), 256, 0, s>>>(w + p.part_off, gamma, save_rstd, w + p.c1_off, w + p.c2_off,
+  norm_bwd_finalize_kernel<<<dim3(cdiv(g->cs, 4), p.G), 256, 0, s>>>(w + p.part_off, gamma, save_rstd, w + p.c1_off, w + p.c2_off,
                                                                         w + p.scale_off, p.Pg, g->C, g->cs, p.nb);
   if (dgamma || dbeta)
     norm_bwd_param_kernel<<<cdiv(g->C, 256), 256, 0, s>>>(w + p.c1_off, w + p.c2_off, dgamma, dbeta, p.G, p.Pg, g->C, g->cs, accumulate);
