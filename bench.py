@@ -341,7 +341,7 @@ def pmc_traffic(family):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
     (profiles/r01_e_pmc_hbm.json: FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled per the gfx950 note in
     MI355X_MICROARCH.md §HBM).  PMC collection cannot run inside the timed process, hence the lookup; None if absent."""
-    path = os.path.join(ROOT, 'profiles', 'r01_d_pmc_hbm.json')
+    path = os.path.join(ROOT, 'profiles', 'r01_e_pmc_hbm.json')
     if not os.path.exists(path):
         return None
     parts = family.split('_')                      # conv_fwd32_4x4x2x2 -> conv_fwd32_kernel<4, 4, 2, 2>
