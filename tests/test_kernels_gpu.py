@@ -289,3 +289,30 @@ def test_errors_are_loud(dev):
         ops.Conv2dFn.apply(torch.zeros(1, 3, 8, 8), torch.zeros(4, 3, 3, 3), None, 1, 1, 0, 0, 0.0)   # CPU tensor: no fallback
     with pytest.raises(RuntimeError):
         ops.Conv2dFn.apply(torch.zeros(1, 3, 8, 8, device=dev), torch.zeros(4, 5, 3, 3, device=dev), None, 1, 1, 0, 0, 0.0)
+
+
+def test_integration_md_stub_runs_verbatim(dev):
+    """The ctypes binding printed in INTEGRATION.md (what a CAT maintainer would paste) must work as written."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, 'INTEGRATION.md')).read()
+    blocks = re.findall(r'```python\n(.*?)```', text, flags=re.S)
+    code = [b for b in blocks if 'def conv2d_nhwc' in b]
+    assert len(code) == 1
+    ns = {}
+    cwd = os.getcwd()
+    os.chdir(root)
+    try:
+        exec(code[0], ns)
+        x = detfill.normal((2, 8, 12, 10), 71)                       # NCHW reference input, 8 channels (already a multiple of 4)
+        w = detfill.normal((5, 8, 3, 3), 72, 0.2)
+        b = detfill.normal((5,), 73, 0.1)
+        y = ns['conv2d_nhwc'](x.permute(0, 2, 3, 1).contiguous().to(dev), w.permute(0, 2, 3, 1).contiguous().to(dev), b.to(dev), 1, 1, True)
+        torch.cuda.synchronize()
+    finally:
+        os.chdir(cwd)
+    ref = F.conv2d(F.pad(x, (1, 1, 1, 1), mode='reflect'), w, b)
+    got = y[..., :5].permute(0, 3, 1, 2).cpu()
+    assert rel(got, ref) < TOL
+    assert float(y[..., 5:].abs().max()) == 0.0                      # padding channels are written as zeros
