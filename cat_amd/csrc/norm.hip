@@ -168,7 +168,8 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void norm_bwd_finalize_kernel(const float* __restrict__ part, const float* __restrict__ gamma,
                                                                 const float* __restrict__ rstd, float* __restrict__ c1,
                                                                 float* __restrict__ c2, float* __restrict__ scale, int Pg, int C, int cs,
-                                                                int nb) {
+                                                                int nb, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                int accumulate) {
   // grid (cdiv(cs,4), G); one wave per channel (see norm_fwd_finalize_kernel): per-(group, channel) means of g and g*xhat
   const int g = blockIdx.y, c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (c >= cs) return;
@@ -187,6 +188,10 @@ __global__ __launch_bounds__(256) void norm_bwd_finalize_kernel(const float* __r
   c1[g * cs + c] = s0 * inv;
   c2[g * cs + c] = s1 * inv;
   scale[g * cs + c] = c < C ? (gamma ? gamma[c] : 1.f) * rstd[g * C + c] : 0.f;
+  if (c < C) {   // one statistic group (batch norm): the parameter gradients are these sums -- no separate launch
+    if (dgamma) dgamma[c] = accumulate ? dgamma[c] + s1 : s1;
+    if (dbeta) dbeta[c] = accumulate ? dbeta[c] + s0 : s0;
+  }
 }
 
 // dgamma[c] (+)= sum_g sum(g*xhat), dbeta[c] (+)= sum_g sum(g)  (sums recovered from the per-group means)
@@ -302,9 +307,11 @@ int cat_norm_bwd(const cat_norm_t* g, const float* x, const float* dy, const flo
   hipStream_t s = (hipStream_t)stream;
   norm_stats_kernel<1><<<dim3(p.nb, p.G, p.nz), 256, 0, s>>>(x, dy, gamma, beta, save_mean, save_rstd, w + p.part_off, p.Pg, g->C, g->cs,
                                                               p.zq, p.ppl, p.nb, g->act, g->slope);
+  const bool one_group = p.G == 1;
   norm_bwd_finalize_kernel<<<dim3(cdiv(g->cs, 4), p.G), 256, 0, s>>>(w + p.part_off, gamma, save_rstd, w + p.c1_off, w + p.c2_off,
-                                                                        w + p.scale_off, p.Pg, g->C, g->cs, p.nb);
-  if (dgamma || dbeta)
+                                                                        w + p.scale_off, p.Pg, g->C, g->cs, p.nb, one_group ? dgamma : nullptr,
+                                                                        one_group ? dbeta : nullptr, accumulate);
+  if (!one_group && (dgamma || dbeta))
     norm_bwd_param_kernel<<<cdiv(g->C, 256), 256, 0, s>>>(w + p.c1_off, w + p.c2_off, dgamma, dbeta, p.G, p.Pg, g->C, g->cs, accumulate);
   const int64_t nquads = (int64_t)g->N * g->HW * p.nq;
   norm_bwd_apply_kernel<<<ew_grid(nquads), 256, 0, s>>>(x, dy, gamma, beta, save_mean, save_rstd, w + p.c1_off, w + p.c2_off,

@@ -177,11 +177,12 @@ class ConvTranspose2d(nn.ConvTranspose2d):
             raise NotImplementedError('padding in front of a transposed conv')
         if self.groups != 1 or self.dilation != (1, 1) or self.stride[0] != self.stride[1] or self.padding[0] != self.padding[1]:
             raise NotImplementedError('conv_transpose2d: groups 1, dilation 1, square geometry only')
-        if fold_bn is not None:
+        if fold_bn is not None:      # frozen (eval, no grad): BatchNorm folded into the weights, activation in the kernel epilogue
             weight, bias = _folded_eval_bn(self, fold_bn, 1)
-        else:
-            _to_channels_last_(self)
-            weight, bias = self.weight, self.bias
+            act, slope = _act_code(fuse_act)
+            return ops.ConvTranspose2dFn.apply(x, weight, bias, self.stride[0], self.padding[0], self.output_padding[0], act, slope)
+        _to_channels_last_(self)
+        weight, bias = self.weight, self.bias
         y = ops.ConvTranspose2dFn.apply(x, weight, bias, self.stride[0], self.padding[0], self.output_padding[0])
         if fuse_act is not None:
             act, slope = _act_code(fuse_act)

@@ -342,7 +342,7 @@ class ConvTranspose2dFn(torch.autograd.Function):
     (conv input = our output), backward-data is that conv's forward, backward-weights its wgrad."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, output_padding):
+    def forward(ctx, x, weight, bias, stride, pad, output_padding, act=0, slope=0.0):
         _require_cuda(x)
         x = conform(x)
         wcl, wcs = weight_cl(weight)
@@ -350,11 +350,13 @@ class ConvTranspose2dFn(torch.autograd.Function):
         cin_w, cout_t, kh, kw = weight.shape
         if cin_w != cin_t:
             raise RuntimeError(f'conv_transpose2d: input has {cin_t} channels, weight expects {cin_w}')
+        if act != L.ACT_NONE and torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad):
+            raise NotImplementedError('conv_transpose2d: the fused epilogue activation is the frozen (no-grad) path only')
         ho = (hi - 1) * stride - 2 * pad + kh + output_padding
         wo = (wi - 1) * stride - 2 * pad + kw + output_padding
         y = empty_act(n, cout_t, ho, wo, x.device)
         # equivalent conv: input (ho, wo, cout_t) -> output (hi, wi, cin_t)
-        g = _conv_geom(n, ho, wo, cout_t, act_cs(y), hi, wi, cin_t, act_cs(x), kh, kw, stride, pad, L.PAD_ZERO, wcs=wcs)
+        g = _conv_geom(n, ho, wo, cout_t, act_cs(y), hi, wi, cin_t, act_cs(x), kh, kw, stride, pad, L.PAD_ZERO, act, slope, wcs=wcs)
         L.call('cat_conv2d_dgrad', C.byref(g), _p(x), _p(wcl), _p(bias), _p(y), act_cs(y), act_cs(y), _stream())
         ctx.geom = (n, ho, wo, cout_t, act_cs(y), hi, wi, cin_t, act_cs(x), kh, kw, stride, pad, wcs)
         ctx.weight, ctx.bias = weight, bias
@@ -385,7 +387,7 @@ class ConvTranspose2dFn(torch.autograd.Function):
             ws = workspace(L.query('cat_channel_sum_ws_bytes', m, act_cs(dy)), x.device)
             db = _write_param_grad(ctx.bias, lambda dst, acc: L.call('cat_channel_sum', _p(dy), m, cout_t, act_cs(dy), _p(dst), acc,
                                                                      _p(ws), st))
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None, None
 
 
 class DwConv2dFn(torch.autograd.Function):
