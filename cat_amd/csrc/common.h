@@ -35,7 +35,8 @@ class ProfScope {
 
 // Cout <= 4 direct convolutions (conv_smallco.hip)
 bool smallco_applicable(const cat_conv_t* g);
-int smallco_fwd(const cat_conv_t* g, const float* x, const float* w, const float* bias, float* y, hipStream_t s);
+int smallco_fwd_ksplit(const cat_conv_t* g);   // > 1: channel-split forward, needs ksplit * N*Ho*Wo*ycs floats of workspace
+int smallco_fwd(const cat_conv_t* g, const float* x, const float* w, const float* bias, float* y, float* ws, int ksplit, hipStream_t s);
 int smallco_wgrad_nblk(const cat_conv_t* g);
 int smallco_wgrad(const cat_conv_t* g, const float* x, const float* dy, float* ws, hipStream_t s);
 

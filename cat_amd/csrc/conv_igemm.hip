@@ -695,8 +695,219 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(IgemmArgs p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------ dgrad, BK = 32
+// conv_dgrad_kernel with 32-deep K chunks and parked pointers (see conv_fwd32_kernel), for the wide layers that carry the
+// discriminator's backward pass: Cout % 16 == 0 (every 16-half of a chunk sits inside one tap and c4 == Cout, so validity never
+// changes inside a tap), float4-readable filter rows, BN % 64 == 0.  The N-contiguous B tile is [32 k][BN] WITHOUT row padding
+// (2 x (BM + BN) x 32 floats = 64 KB at 128 x 128): the 16-column group of a row is XOR-ed with (row >> 2) & 3 instead, which puts the
+// four k-rows a wave reads per ds_read_b32 (rows 4 apart) into four different 16-bank groups.
+template <int MT, int NT, int WM, int WN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_dgrad32_kernel(IgemmArgs p) {
+  constexpr int BM = WM * MT * 16, BN = WN * NT * 16;
+  static_assert(BN % 64 == 0 && 256 % (BN / 4) == 0, "B tile swizzle needs 64-column multiples");
+  constexpr int AI = BM / 32;
+  constexpr int BQ = BN / 4;          // float4 per k-row of the B tile
+  constexpr int BR = 256 / BQ;        // k-rows staged per pass of the workgroup
+  constexpr int BI = 32 / BR;         // float4 per thread
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sA = smem;
+  float* sB = smem + 2 * BM * 32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int s = p.stride;
+  const int py = blockIdx.y / s, px = blockIdx.y % s;
+  const int iyf = ((py - p.pad_eff) % s + s) % s, ixf = ((px - p.pad_eff) % s + s) % s;
+  const int Hc = iyf < p.Hin ? (p.Hin - iyf + s - 1) / s : 0, Wc = ixf < p.Win ? (p.Win - ixf + s - 1) / s : 0;
+  const int cy0 = (iyf + p.pad_eff - py) / s, cx0 = (ixf + p.pad_eff - px) / s;
+  const int nty = py < p.kh ? (p.kh - py + s - 1) / s : 0, ntx = px < p.kw ? (p.kw - px + s - 1) / s : 0;
+  const int ntaps = nty * ntx, ntxd = ntx > 0 ? ntx : 1;
+  const int K = ntaps * p.c4;
+  const int Mc = p.N * Hc * Wc;
+  const int ntn = (p.Cin + BN - 1) / BN;
+  const int bid = cat::xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (bid / ntn) * BM, n0 = (bid % ntn) * BN;
+  if (m0 >= Mc) return;
+  const int half = __builtin_amdgcn_readfirstlane(wave >> 1);
+  const int q4 = tid & 3, q = half * 4 + q4, r0 = (tid & 127) >> 2;
+  const int HcWc = Hc * Wc;
+  const int taps = p.kh * p.kw;
+
+  int cy[AI], cx[AI];
+  int64_t aoff[AI];
+  bool rv[AI];
+#pragma unroll
+  for (int i = 0; i < AI; ++i) {
+    const int m = m0 + r0 + 32 * i;
+    rv[i] = m < Mc;
+    const int mm = rv[i] ? m : 0;
+    const int n = mm / HcWc, rem = mm - n * HcWc;
+    const int a = rem / Wc, b = rem - a * Wc;
+    cy[i] = cy0 + a;
+    cx[i] = cx0 + b;
+    aoff[i] = (int64_t)n * p.Ho * p.Wo * p.ycs;
+  }
+
+  // A walk: this thread's quad = (class tap atj = (ajy, ajx), channels aco .. aco+3 of dy), advanced by 32 per chunk
+  int atj, aco, ajy, ajx;
+  {
+    const int ka = q * 4;
+    atj = ka / p.c4;
+    aco = ka - atj * p.c4;
+    ajy = atj / ntxd;
+    ajx = atj - ajy * ntxd;
+  }
+  const float* pa[AI];
+  int inca[AI];
+  auto locate_a = [&]() {
+    const bool tv = atj < ntaps;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const int oy = cy[i] - ajy, ox = cx[i] - ajx;
+      const bool v = rv[i] && tv && (unsigned)oy < (unsigned)p.Ho && (unsigned)ox < (unsigned)p.Wo;
+      pa[i] = v ? p.a + aoff[i] + ((int64_t)oy * p.Wo + ox) * p.ycs + aco : g_zero_page;
+      inca[i] = v ? 32 : 0;
+    }
+  };
+  locate_a();
+  // B walk: k-row (class tap btj, filter bco) x float4 of input channels; one filter row = taps * wcs floats
+  const int nq = tid % BQ, bci = n0 + nq * 4;
+  const bool bcv = bci < p.Cin;
+  const int bstep = 32 * taps * p.wcs;   // < 2^31 (checked on the host)
+  int btj[BI], bco[BI];
+  const float* pb[BI];
+  int incb[BI];
+  auto locate_b = [&](int i) {
+    const int jy = btj[i] / ntxd, jx = btj[i] - jy * ntxd;
+    const int ky = py + jy * s, kx = px + jx * s;
+    const bool v = bcv && btj[i] < ntaps;
+    pb[i] = v ? p.b + ((int64_t)bco[i] * taps + ky * p.kw + kx) * p.wcs + bci : g_zero_page;
+    incb[i] = v ? bstep : 0;
+  };
+#pragma unroll
+  for (int i = 0; i < BI; ++i) {
+    const int kr = tid / BQ + BR * i;
+    btj[i] = kr / p.c4;
+    bco[i] = kr - btj[i] * p.c4;
+    locate_b(i);
+  }
+
+  f4 ra[AI], rb[BI];
+  auto gload = [&]() {
+#pragma unroll
+    for (int i = 0; i < AI; ++i) ra[i] = ldg4(pa[i]);
+#pragma unroll
+    for (int i = 0; i < BI; ++i) rb[i] = ldg4(pb[i]);
+    aco += 32;
+    if (aco >= p.c4) {   // wave-uniform: the 16 k of this wave's half sit in one tap
+      do {
+        aco -= p.c4;
+        ++atj;
+        if (++ajx == ntxd) {
+          ajx = 0;
+          ++ajy;
+        }
+      } while (aco >= p.c4);
+      locate_a();
+    } else {
+#pragma unroll
+      for (int i = 0; i < AI; ++i) pa[i] += inca[i];
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      bco[i] += 32;
+      if (bco[i] >= p.c4) {   // wave-uniform as well (a wave stages rows of one 16-group per pass)
+        do {
+          bco[i] -= p.c4;
+          ++btj[i];
+        } while (bco[i] >= p.c4);
+        locate_b(i);
+      } else {
+        pb[i] += incb[i];
+      }
+    }
+  };
+  auto sstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < AI; ++i) *reinterpret_cast<f4*>(sA + buf * BM * 32 + swz32(r0 + 32 * i, q)) = ra[i];
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      const int kr = tid / BQ + BR * i;
+      *reinterpret_cast<f4*>(sB + buf * 32 * BN + kr * BN + ((nq * 4) ^ (((kr >> 2) & 3) << 4))) = rb[i];
+    }
+  };
+
+  f4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+
+  const int lr = lane & 15, lq = lane >> 4;
+  auto mma = [&](int buf) {
+    const float* A = sA + buf * BM * 32;
+    const float* B = sB + buf * 32 * BN;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      f4 fa[MT];
+      float fb[NT][4];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const f4*>(A + swz32(wm * MT * 16 + i * 16 + lr, lq + 4 * h));
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) fb[j][t] = B[(h * 16 + lq * 4 + t) * BN + ((wn * NT * 16 + j * 16 + lr) ^ (lq << 4))];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][t], fb[j][t], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  const int nk = (K + 31) >> 5;   // a trailing half chunk has tap == ntaps: parked on the zero page
+  if (nk > 0) {
+    gload();
+    sstore(0);
+    __syncthreads();
+    for (int kc = 0; kc + 1 < nk; ++kc) {
+      const int buf = kc & 1;
+      gload();
+      mma(buf);
+      __builtin_amdgcn_sched_barrier(0);
+      sstore(buf ^ 1);
+      __syncthreads();
+    }
+    mma((nk - 1) & 1);
+  }
+
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      const int m = m0 + wm * MT * 16 + i * 16 + lq * 4 + rg;
+      if (m >= Mc) continue;
+      const int n = m / HcWc, rem = m - n * HcWc;
+      const int a = rem / Wc, b = rem - a * Wc;
+      float* orow = p.out + (((int64_t)n * p.Hin + (iyf + a * s)) * p.Win + (ixf + b * s)) * p.ocs;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int col = n0 + wn * NT * 16 + j * 16 + lr;
+        if (col < p.Cin) {
+          const float bias = p.bias ? p.bias[col] : 0.f;
+          orow[col] = cat::apply_act(acc[i][j][rg] + bias, p.act, p.slope);
+        } else if (col < p.cw) {
+          orow[col] = 0.f;
+        }
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ wgrad
 // rows = Cout (BM), cols = K = taps*cin4 (BN), reduction over the pixels [y*mchunk, (y+1)*mchunk).
+// (A 32-pixel-chunk variant of the 128 x 128 tile was measured 1.5 - 7 % SLOWER on every wide layer: this kernel is bound by the
+// per-pixel gather arithmetic on the vector ALU, which a deeper chunk does not reduce, not by barriers.)
 template <int MT, int NT, int WM, int WN>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(IgemmArgs p) {
   constexpr int BM = WM * MT * 16, BN = WN * NT * 16, LDA = BM + 4, LDB = BN + 4;
@@ -1039,7 +1250,12 @@ static int fwd_setup(IgemmArgs& a, const cat_conv_t* g) {
 
 size_t cat_conv2d_fwd_ws_bytes(const cat_conv_t* g) {
   IgemmArgs a{};
-  if (fwd_setup(a, g) || cat::smallco_applicable(g) || !fwd_bk32_ok(a)) return 0;
+  if (fwd_setup(a, g)) return 0;
+  if (cat::smallco_applicable(g)) {
+    const int ks = cat::smallco_fwd_ksplit(g);
+    return ks > 1 ? (size_t)ks * a.M * g->ycs * sizeof(float) : 0;
+  }
+  if (!fwd_bk32_ok(a)) return 0;
   const SplitPlan sp = split_plan(a.M, a.Cout, (a.K + 31) >> 5);
   return sp.ksplit > 1 ? (size_t)sp.ksplit * a.M * g->ycs * sizeof(float) : 0;
 }
@@ -1065,7 +1281,14 @@ static int conv_fwd_impl(const cat_conv_t* g, const float* x, const float* w, co
   hipStream_t s = (hipStream_t)stream;
   if (cat::smallco_applicable(g)) {
     cat::ProfScope prof("conv_fwd_smallco", 2.0 * (double)g->N * g->Ho * g->Wo * g->Cout * g->kh * g->kw * g->Cin, 0.0, stream);
-    return cat::smallco_fwd(g, x, w, bias, y, s);
+    const int ks = ws ? cat::smallco_fwd_ksplit(g) : 1;
+    if (int e = cat::smallco_fwd(g, x, w, bias, y, (float*)ws, ks, s)) return e;
+    if (ks > 1) {
+      splitk_reduce_kernel<<<reduce_grid((int64_t)a.M * ((a.cw + 3) / 4)), 256, 0, s>>>((const float*)ws, bias, y, a.M, a.Cout, a.cw, a.ycs, ks, a.act,
+                                                                                         a.slope);
+      return cat::check_launch("conv2d_fwd_smallco_reduce");
+    }
+    return 0;
   }
   const double prof_flops = 2.0 * (double)g->N * g->Ho * g->Wo * g->Cout * g->kh * g->kw * g->Cin;
   static const int sched = getenv("CAT_SCHED") ? atoi(getenv("CAT_SCHED")) : 0;
@@ -1196,6 +1419,20 @@ static int conv_dgrad_impl(const cat_conv_t* g, const float* dy, const float* w,
       splitk_reduce_kernel<<<reduce_grid(P * ((a.cw + 3) / 4)), 256, 0, s>>>(a.part, a.bias, a.out, P, a.Cin, a.cw, a.ocs, a.ksplit, a.act,  \
                                                                             a.slope);      \
     }                                                                                      \
+  }
+  // BK = 32 variant of the 128 x 128 tile (the discriminator's and the teacher's wide layers)
+  static const int bk32 = getenv("CAT_DGRAD_BK32") ? atoi(getenv("CAT_DGRAD_BK32")) : 1;
+  if (bk32 && a.ksplit == 1 && a.Cin > 96 && a.wvec && g->Cout % 16 == 0 && g->Cin % 4 == 0) {
+    cat::ProfScope prof("conv_dgrad32_4x4x2x2", prof_flops, 0.0, stream);
+    const dim3 grid(cdiv(mmax, 128) * cdiv(a.Cin, 128), st * st);
+    const size_t lds = (size_t)2 * (128 + 128) * 32 * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)conv_dgrad32_kernel<4, 4, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr_set = true;
+    }
+    conv_dgrad32_kernel<4, 4, 2, 2><<<grid, 256, lds, s>>>(a);
+    return cat::check_launch("conv2d_dgrad");
   }
   if (use_small_m(mmax, a.Cin)) DISPATCH_TILE_N_SMALLM(a.Cin, LAUNCH);
   else DISPATCH_TILE_N(a.Cin, LAUNCH);

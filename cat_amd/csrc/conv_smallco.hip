@@ -8,6 +8,7 @@
 //   wgrad   : thread = (tap, channel quad) accumulates dw over the pixels of many tiles; LDS tile layout [pixel][quad]
 // dgrad of these layers has GEMM-N = Cin (large) and stays on the implicit-GEMM kernel.
 #include "common.h"
+#include <stdlib.h>
 
 namespace cat_smallco {
 
@@ -16,6 +17,7 @@ struct Args {
   int N, H, W, Cin, xcs, Ho, Wo, Cout, ycs, kh, kw, pad, reflect, act;
   float slope;
   int cw, c4, tiles_x, tiles_y, nblk, wcs;
+  int ksplit, qchunk;   // forward split over input-channel quads: blockIdx.z = slice of qchunk quads, raw sums to part[z][pixel][ycs]
 };
 
 __device__ __forceinline__ int src_index(int i, int n, int reflect) {  // -1 = zero padding
@@ -44,8 +46,9 @@ __global__ __launch_bounds__(256) void fwd_kernel(Args p) {
 #pragma unroll
     for (int c = 0; c < CO; ++c) acc[i][c] = 0.f;
   const float* xn = p.x + (int64_t)n * p.H * p.W * p.xcs;
-  const int nquads = p.c4 / 4;
-  for (int q0 = 0; q0 < nquads; q0 += CKQ) {
+  const int qbeg = p.ksplit > 1 ? (int)blockIdx.z * p.qchunk : 0;
+  const int nquads = p.ksplit > 1 ? min(p.c4 / 4, qbeg + p.qchunk) : p.c4 / 4;
+  for (int q0 = qbeg; q0 < nquads; q0 += CKQ) {
     const int nq = min(CKQ, nquads - q0);
     // stage the chunk: all global loads of a thread are issued before the first LDS store (one latency, not ITERS)
     constexpr int ITERS = (TR * NC * CKQ + 255) / 256;
@@ -124,7 +127,14 @@ __global__ __launch_bounds__(256) void fwd_kernel(Args p) {
   for (int i = 0; i < 4; ++i) {
     const int ox = ox0 + sx + 8 * i;
     if (ox >= p.Wo) continue;
-    float* yo = p.y + (((int64_t)n * p.Ho + oy) * p.Wo + ox) * p.ycs;
+    const int64_t pix = ((int64_t)n * p.Ho + oy) * p.Wo + ox;
+    if (p.ksplit > 1) {   // raw partial sums of this channel slice; bias / activation / pad lanes in the shared split-K reduce
+      float* po = p.part + ((int64_t)blockIdx.z * p.N * p.Ho * p.Wo + pix) * p.ycs;
+#pragma unroll
+      for (int c = 0; c < CO; ++c) po[c] = acc[i][c];
+      continue;
+    }
+    float* yo = p.y + pix * p.ycs;
 #pragma unroll
     for (int c = 0; c < CO; ++c) yo[c] = cat::apply_act(acc[i][c] + (p.bias ? p.bias[c] : 0.f), p.act, p.slope);
     for (int c = CO; c < p.cw; ++c) yo[c] = 0.f;
@@ -230,7 +240,7 @@ static void launch_fwd(cat_smallco::Args& a, const cat_conv_t* g, bool small_ima
   a.tiles_x = cdiv(g->Wo, 32);
   if (small_image) {   // few pixels, many channels: 8-row tiles, 4 channel groups
     a.tiles_y = cdiv(g->Ho, 8);
-    cat_smallco::fwd_kernel<CO, 8, 4, 8, KW, WVEC><<<dim3(a.tiles_x * a.tiles_y, g->N), 256, 0, s>>>(a);
+    cat_smallco::fwd_kernel<CO, 8, 4, 8, KW, WVEC><<<dim3(a.tiles_x * a.tiles_y, g->N, a.ksplit > 1 ? a.ksplit : 1), 256, 0, s>>>(a);
   } else {
     a.tiles_y = cdiv(g->Ho, 32);
     cat_smallco::fwd_kernel<CO, 32, 1, 2, KW, WVEC><<<dim3(a.tiles_x * a.tiles_y, g->N), 256, 0, s>>>(a);
@@ -243,11 +253,35 @@ static void launch_fwd_v(cat_smallco::Args& a, const cat_conv_t* g, bool sm, hip
   else launch_fwd<CO, KW, false>(a, g, sm, s);
 }
 
-int smallco_fwd(const cat_conv_t* g, const float* x, const float* w, const float* bias, float* y, hipStream_t s) {
+static bool fwd_small_image(const cat_conv_t* g) { return g->Cin >= 64 && (int64_t)g->N * cdiv(g->Ho, 32) * cdiv(g->Wo, 32) < 256; }
+
+// PatchGAN's head at batch 16 is 64 workgroups walking 32 channel chunks each: with a workspace the channel range is cut into
+// slices of >= 2 chunks (8 quads each) until ~512 workgroups exist
+int smallco_fwd_ksplit(const cat_conv_t* g) {
+  static const int on = getenv("CAT_SMALLCO_SPLITK") ? atoi(getenv("CAT_SMALLCO_SPLITK")) : 1;
+  if (!on || !fwd_small_image(g)) return 1;
+  const int blocks = g->N * cdiv(g->Ho, 8) * cdiv(g->Wo, 32);
+  const int chunks = cdiv(((g->Cin + 3) & ~3) / 4, 8);
+  int ks = cdiv(512, blocks);
+  if (ks > chunks / 2) ks = chunks / 2;
+  if (ks < 2) return 1;
+  const int per = cdiv(chunks, ks);
+  ks = cdiv(chunks, per);
+  return ks < 2 ? 1 : ks;
+}
+
+int smallco_fwd(const cat_conv_t* g, const float* x, const float* w, const float* bias, float* y, float* ws, int ksplit, hipStream_t s) {
   cat_smallco::Args a = make_args(g);
   a.x = x; a.w = w; a.bias = bias; a.y = y;
   a.cw = g->ycw > g->Cout ? g->ycw : g->Cout;
-  const bool sm = g->Cin >= 64 && (int64_t)g->N * cdiv(g->Ho, 32) * cdiv(g->Wo, 32) < 256;
+  const bool sm = fwd_small_image(g);
+  a.ksplit = 1;
+  if (sm && ws && ksplit > 1) {
+    const int chunks = cdiv(((g->Cin + 3) & ~3) / 4, 8);
+    a.ksplit = ksplit;
+    a.qchunk = cdiv(chunks, ksplit) * 8;
+    a.part = ws;
+  }
   if (g->Cout == 1 && g->kh == 4) launch_fwd_v<1, 4>(a, g, sm, s);
   else if (g->Cout == 1 && g->kh == 7) launch_fwd_v<1, 7>(a, g, sm, s);
   else if (g->Cout == 3 && g->kh == 4) launch_fwd_v<3, 4>(a, g, sm, s);

@@ -61,6 +61,14 @@ CONV_CASES = [
     (512, 31, 1, 1, 0, False, 0, 2, 8, 8),
     (7, 512, 5, 1, 2, False, 0, 4, 4, 8),
     (96, 16, 3, 1, 1, True, 0, 1, 6, 6),
+    # wide layers: 32-deep dgrad / wgrad chunks (tails in K, Cin, Cout; reflect; direct single-slice wgrad), channel-split head
+    (128, 64, 3, 1, 1, True, 0, 2, 9, 7),
+    (132, 48, 3, 1, 1, False, 0, 1, 10, 12),
+    (100, 132, 3, 1, 1, True, 0, 2, 9, 9),
+    (160, 112, 1, 1, 0, False, 0, 1, 5, 5),
+    (256, 128, 4, 1, 1, False, 2, 3, 12, 10),
+    (1024, 1, 4, 1, 1, False, 0, 4, 12, 12),
+    (512, 1, 4, 1, 2, False, 0, 2, 9, 17),
 ]
 
 

@@ -73,7 +73,7 @@ def main():
             flops = 2.0 * n * ho * wo * cout * k * k * cin
             P = lambda t: C.c_void_p(t.data_ptr())
             fns = {
-                'fwd': lambda: L.call('cat_conv2d_fwd', C.byref(g), P(x), P(wt), None, P(y), st),
+                'fwd': lambda: ops._conv_fwd(g, x, wt, None, y, st),
                 'dgrad': lambda: L.call('cat_conv2d_dgrad', C.byref(g), P(dy), P(wt), None, P(dx), ops.act_cs(dx), ops.act_cs(dx), st),
                 'wgrad': lambda: L.call('cat_conv2d_wgrad', C.byref(g), P(x), P(dy), P(dw), 0, P(ws), st),
             }
