@@ -1221,9 +1221,15 @@ WgradPlan wgrad_plan(const cat_conv_t* g) {
   WgradPlan pl;
   pl.tiles = cdiv(Cout, BM) * cdiv(K, BN);
   const int M = g->N * g->Ho * g->Wo;
-  int ns = cdiv(1024, pl.tiles);
-  int maxs = M / 256 > 0 ? M / 256 : 1;
-  if (maxs > 256) maxs = 256;
+  const char* tenv = getenv("CAT_WGRAD_BLOCKS");   // workgroups the pixel split aims for (tuning knob, read per call)
+  const int target = tenv ? atoi(tenv) : 1024;
+  int ns = cdiv(target > 0 ? target : 1024, pl.tiles);
+  const char* cenv = getenv("CAT_WGRAD_MINCHUNK");   // fewest pixels per slice (tuning knob)
+  const int minchunk = cenv && atoi(cenv) >= 16 ? atoi(cenv) : 256;
+  int maxs = M / minchunk > 0 ? M / minchunk : 1;
+  const char* senv = getenv("CAT_WGRAD_MAXSPLIT");
+  const int maxsplit = senv && atoi(senv) >= 1 ? atoi(senv) : 256;
+  if (maxs > maxsplit) maxs = maxsplit;
   if (ns > maxs) ns = maxs;
   if (ns < 1) ns = 1;
   pl.mchunk = cat::round_up(cdiv(M, ns), 16);
