@@ -21,7 +21,6 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 import torch  # noqa: E402
 
@@ -29,17 +28,16 @@ MFMA_F32_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_
 
 
 def build_model(args, device_index):
-    import helpers as H
-    from oracle import detfill
-    from cat_amd import networks, prune
+    """BASELINE configs[1]: canonical teacher, student pruned from it, PatchGAN, both optimizers."""
+    from cat_amd import networks, prune, synthetic
     from cat_amd.distillers import create_distiller
-    opt = H.make_opt(norm='batch', track=True, ndf=128, dataset_mode='aligned', gan_mode='hinge', lambda_recon=100.0, lambda_distill=1.3,
-                     target_flops=args.target_flops, prune_cin_lb=16, student_ngf=32, gpu_ids=[device_index],
-                     data_height=args.size, data_width=args.size)
+    opt = synthetic.default_options(norm='batch', track=True, ndf=128, dataset_mode='aligned', gan_mode='hinge', lambda_recon=100.0,
+                                    lambda_distill=1.3, target_flops=args.target_flops, prune_cin_lb=16, student_ngf=32,
+                                    gpu_ids=[device_index], data_height=args.size, data_width=args.size)
     torch.manual_seed(233)
     model = create_distiller(opt, verbose=False)
     # canonical teacher: deterministic weights, |N(0,1)| norm scales (a trained teacher's scales are non-uniform)
-    model.netG_teacher.load_state_dict(detfill.fill_state_dict(model.netG_teacher.state_dict(), H.SEED_T, gamma_abs_normal=True))
+    model.netG_teacher.load_state_dict(synthetic.fill_state_dict(model.netG_teacher.state_dict(), synthetic.SEED_TEACHER, gamma_abs_normal=True))
     model.setup(opt, verbose=False)
     # student shapes are defined at 256x256 like the reference's launch scripts (data_height is the dataset's size)
     opt.data_height = opt.data_width = 256
@@ -63,11 +61,9 @@ def build_spade_model(args, device_index):
     batch 4 -- frozen teacher ngf 64, student ngf 48 pruned by shrink_spade_model to 5.6e9 MACs (the launch script's budget),
     multiscale spectral-norm PatchGAN ndf 64, hinge + feature matching + VGG + KA.  VGG19 carries random weights of the real
     topology (no network to fetch torchvision's): same kernels, same FLOPs."""
-    import helpers as H
-    from oracle import detfill
-    from cat_amd import prune
+    from cat_amd import prune, synthetic
     from cat_amd.distillers import create_distiller
-    opt = H.make_opt(norm='instance', gpu_ids=[device_index])
+    opt = synthetic.default_options(norm='instance', gpu_ids=[device_index])
     opt.__dict__.update(dict(
         distiller='spade', input_nc=35, output_nc=3, semantic_nc=36, contain_dontcare_label=False, no_instance=False,
         teacher_ngf=64, student_ngf=48, pretrained_ngf=64, teacher_netG='inception_spade', student_netG='inception_spade',
@@ -80,7 +76,7 @@ def build_spade_model(args, device_index):
     torch.manual_seed(233)
     model = create_distiller(opt, verbose=False)
     m = model.modules_on_one_gpu
-    m.netG_teacher.load_state_dict(detfill.fill_state_dict(m.netG_teacher.state_dict(), 111, gamma_abs_normal=True))
+    m.netG_teacher.load_state_dict(synthetic.fill_state_dict(m.netG_teacher.state_dict(), synthetic.SEED_TEACHER_SPADE, gamma_abs_normal=True))
     model.setup(opt, verbose=False)
     opt.data_height, opt.data_width = 256, 512          # student shapes are defined at the dataset's size (launch script)
     prune.shrink(model, opt)
@@ -88,17 +84,14 @@ def build_spade_model(args, device_index):
     return model, opt
 
 
-def spade_batches(args, rank, nbuf):
-    import numpy as np
-    from oracle import detfill
+def spade_batches(args, rank, nbuf, device='cuda'):
+    from cat_amd import synthetic
     h, w = args.size, 2 * args.size
     out = []
     for i in range(nbuf):
-        rng = np.random.default_rng(3000 + 10 * i + rank)
-        lab = np.repeat(np.repeat(rng.integers(0, 35, (args.batch, 1, h // 16, w // 16)), 16, 2), 16, 3).astype(np.int32)
-        ins = np.repeat(np.repeat(rng.integers(0, 1000, (args.batch, 1, h // 16, w // 16)), 16, 2), 16, 3).astype(np.int32)
-        out.append({'label': torch.from_numpy(lab).cuda(), 'instance': torch.from_numpy(ins).cuda(),
-                    'image': detfill.images((args.batch, 3, h, w), 4000 + 10 * i + rank).cuda(), 'path': []})
+        lab, ins = synthetic.label_maps(args.batch, h, w, 3000 + 10 * i + rank)
+        out.append({'label': lab.to(device), 'instance': ins.to(device),
+                    'image': synthetic.images((args.batch, 3, h, w), 4000 + 10 * i + rank).to(device), 'path': []})
     return out
 
 
@@ -131,10 +124,9 @@ def cpu_baseline_spade(opt, model, args):
 def cpu_baseline(opt, model, args):
     """The CPU oracle (a port: plain PyTorch ATen ops, same algorithm) on a bounded sample: batch 2 at the bench
     resolution, 1 warm-up + 2 timed steps (~10-30 s of host work)."""
-    import helpers as H
     from oracle import detfill, ref_cpu
     nb = 2
-    ncfg = H.cfg_for('batch')
+    ncfg = {'norm': 'batch', 'eps': opt.norm_epsilon, 'momentum': opt.norm_momentum}
     cfg = dict(T=ncfg, S=ncfg, D=ncfg, dataset_mode='aligned', gan_mode='hinge', lambda_recon=100.0, lambda_distill=1.3, lambda_gan=1.0,
                lr=opt.lr, beta1=opt.beta1)
     cpu = lambda net: {k: v.detach().cpu().contiguous().clone() for k, v in net.state_dict().items()}
@@ -185,7 +177,7 @@ def main():
         raise SystemExit('bench.py needs an MI355X: the product path is HIP-only')
     os.environ['LOCAL_RANK'] = str(local)
     torch.cuda.set_device(local)
-    from oracle import detfill
+    from cat_amd import synthetic
     model, opt = (build_spade_model if spade else build_model)(args, local)
     if args.no_overlap:
         model.teacher_side_stream = False
@@ -203,8 +195,8 @@ def main():
     if spade:
         batches = spade_batches(args, rank, nbuf)
     for i in range(0 if spade else nbuf):
-        A = detfill.images((args.batch, 3, args.size, args.size), 1000 + 10 * i + rank).cuda()
-        B = detfill.images((args.batch, 3, args.size, args.size), 2000 + 10 * i + rank).cuda()
+        A = synthetic.images((args.batch, 3, args.size, args.size), 1000 + 10 * i + rank).cuda()
+        B = synthetic.images((args.batch, 3, args.size, args.size), 2000 + 10 * i + rank).cuda()
         batches.append({'A': A, 'B': B, 'A_paths': [], 'B_paths': []})
 
     def eager_step(i):

@@ -27,21 +27,9 @@ def sd_from_shapes(js):
 
 
 def make_opt(norm='instance', track=False, **kw):
-    opt = Namespace(
-        input_nc=3, output_nc=3, teacher_ngf=64, student_ngf=20, pretrained_ngf=64,
-        teacher_netG='inception_9blocks', student_netG='inception_9blocks', pretrained_netG='inception_9blocks',
-        norm=norm, norm_affine=True, norm_affine_D=True, norm_track_running_stats=track,
-        norm_momentum=0.1, norm_epsilon=1e-5, channels=None, channels_reduction_factor=6,
-        kernel_sizes=[1, 3, 5], active_fn='nn.ReLU', active_fn_D='nn.LeakyReLU',
-        teacher_dropout_rate=0, student_dropout_rate=0, init_type='normal', init_gain=0.02,
-        gpu_ids=[0], ndf=128, netD='n_layers', n_layers_D=3, gan_mode='hinge',
-        dataset_mode='aligned', direction='AtoB', lambda_distill=1.0, lambda_recon=100.0, lambda_gan=1.0,
-        recon_loss_type='l1', distill_G_loss_type='ka', lr=2e-4, beta1=0.5, lr_policy='linear',
-        nepochs=5, nepochs_decay=15, prune_cin_lb=16, target_flops=2.6e9,
-        data_height=256, data_width=256, data_channel=3, prune_logging_verbose=False, isTrain=True,
-        distiller='inception', log_dir='/tmp/cat_amd_logs')
-    opt.__dict__.update(kw)
-    return opt
+    """The launch-script option set (one definition: cat_amd.synthetic.default_options, which bench.py uses as well)."""
+    from cat_amd import synthetic
+    return synthetic.default_options(norm=norm, track=track, **kw)
 
 
 def teacher_sd(opt):

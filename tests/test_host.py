@@ -1,6 +1,7 @@
 """CPU: host-side logic of the drop-in boundary -- state_dict key / shape parity with the reference networks, the
 distiller factory and flag surface, fused-Sequential structure, loud failure without a GPU."""
 import argparse
+import os
 
 import pytest
 import torch
@@ -88,3 +89,49 @@ def test_loss_value_arithmetic():
     a, b = torch.tensor(2.0), torch.tensor(3.0)
     v = LossValue([(0.5, a), (0.5, b)])
     assert float(v) == 2.5 and float(v * 2) == 5.0 and float(v + LossValue([(1.0, a)]) + 0) == 4.5
+
+
+def test_synthetic_fills_match_the_oracle_side_copy():
+    """cat_amd.synthetic (bench / smoke inputs) and oracle/detfill.py (fixtures) are the same fills, kept apart so that nothing on
+    the measured path imports oracle/."""
+    from cat_amd import synthetic
+    from oracle import detfill
+    for seed in (1, 7):
+        assert torch.equal(synthetic.images((2, 3, 8, 8), seed), detfill.images((2, 3, 8, 8), seed))
+        assert torch.equal(synthetic.normal((5,), seed, 0.3), detfill.normal((5,), seed, 0.3))
+    sd = {'a.weight': torch.zeros(4, 3, 3, 3), 'a.bias': torch.zeros(4), 'n.weight': torch.zeros(4), 'n.running_var': torch.zeros(4),
+          'n.running_mean': torch.zeros(4), 'n.num_batches_tracked': torch.zeros((), dtype=torch.long)}
+    for gam in (False, True):
+        a, b = synthetic.fill_state_dict(sd, 5, gam), detfill.fill_state_dict(sd, 5, gam)
+        assert all(torch.equal(a[k], b[k]) for k in sd)
+    assert synthetic.SEED_TEACHER == H.SEED_T
+    lab, ins = synthetic.label_maps(2, 32, 64, 3)
+    assert lab.shape == (2, 1, 32, 64) and lab.dtype == torch.int32 and int(lab.max()) < 35 and int(ins.max()) < 1000
+    assert bool((lab[:, :, :16, :16] == lab[:, :, :1, :1]).all())
+
+
+def test_bench_measured_path_does_not_touch_the_oracle():
+    """Only the cpu_baseline legs of bench.py may import oracle/ (and nothing may import tests/): checked on the AST."""
+    import ast
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tree = ast.parse(open(os.path.join(root, 'bench.py')).read())
+
+    def imports(node):
+        out = []
+        for x in ast.walk(node):
+            if isinstance(x, ast.Import):
+                out += [a.name.split('.')[0] for a in x.names]
+            elif isinstance(x, ast.ImportFrom) and x.module:
+                out.append(x.module.split('.')[0])
+        return out
+    for node in tree.body:
+        names = imports(node)
+        assert 'helpers' not in names and 'tests' not in names
+        if 'oracle' in names:
+            assert isinstance(node, ast.FunctionDef) and node.name.startswith('cpu_baseline'), getattr(node, 'name', node)
+    # the product package never imports the oracle either
+    pkg = os.path.join(root, 'cat_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith('.py'):
+                assert 'oracle' not in imports(ast.parse(open(os.path.join(dirpath, f)).read())), f
