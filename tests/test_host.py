@@ -135,3 +135,20 @@ def test_bench_measured_path_does_not_touch_the_oracle():
         for f in files:
             if f.endswith('.py'):
                 assert 'oracle' not in imports(ast.parse(open(os.path.join(dirpath, f)).read())), f
+
+
+def test_no_undefined_names_in_gpu_only_code():
+    """Most of cat_amd/ only executes on an MI355X; a scope-aware undefined-name pass over the sources (tools/lint_names.py) keeps
+    typos in those branches from surfacing first on the GPU box."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('lint_names', os.path.join(root, 'tools', 'lint_names.py'))
+    lint = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lint)
+    bad = []
+    for top in ('cat_amd', 'bench.py', '__graft_entry__.py', 'oracle', 'tests'):
+        path = os.path.join(root, top)
+        files = [path] if path.endswith('.py') else [os.path.join(d, f) for d, _, fs in os.walk(path) for f in fs if f.endswith('.py')]
+        for f in files:
+            bad += [(os.path.relpath(f, root), line, name) for line, name in lint.check(f)]
+    assert not bad, bad
