@@ -47,3 +47,55 @@ def test_product_does_not_import_the_oracle():
             if f.endswith('.py'):
                 src = open(os.path.join(dirpath, f)).read()
                 assert 'oracle' not in re.sub(r'""".*?"""', '', src, flags=re.S), f
+
+
+def _header_prototypes():
+    text = open(os.path.join(ROOT, 'include', 'cat_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    text = re.sub(r'//[^\n]*', '', text)
+    protos = {}
+    for ret, name, args in re.findall(r'([A-Za-z_][A-Za-z0-9_ \*]*?)\s*\b(cat_[a-z0-9_]+)\s*\(([^)]*)\)\s*;', text):
+        args = [a.strip() for a in args.split(',')] if args.strip() not in ('', 'void') else []
+        protos[name] = (ret.strip(), args)
+    return protos
+
+
+def _kind(ctype_decl):
+    """'p' pointer-sized handle, 'i' int, 'f' float, 'l' 64-bit int, 'z' size_t, 'd' double"""
+    d = ctype_decl.replace('const', ' ').strip()
+    if '*' in d or d.startswith('cat_stream_t'):
+        return 'p'
+    base = d.split()[0] if len(d.split()) == 1 else ' '.join(d.split()[:-1])
+    return {'int': 'i', 'float': 'f', 'int64_t': 'l', 'long long': 'l', 'size_t': 'z', 'double': 'd', 'char': 'p'}[base]
+
+
+def test_ctypes_argument_lists_match_the_header():
+    """Same number of arguments, same kinds, in the same order as the prototypes in include/cat_hip.h: a mismatch would only show as a
+    crash on the GPU box."""
+    import ctypes as C
+    kinds = {C.c_int: 'i', C.c_float: 'f', C.c_int64: 'l', C.c_size_t: 'z', C.c_double: 'd', C.c_void_p: 'p', C.c_char_p: 'p'}
+    protos = _header_prototypes()
+    assert sorted(protos) == sorted(_lib.SIGNATURES)
+    for name, (restype, argtypes) in _lib.SIGNATURES.items():
+        ret, args = protos[name]
+        want = [_kind(a) for a in args]
+        got = [kinds.get(t, 'p') for t in argtypes]      # POINTER(struct) and friends are pointers
+        assert got == want, f'{name}: ctypes {got} vs header {want}'
+        rk = 'p' if '*' in ret else {'int': 'i', 'size_t': 'z', 'void': 'v', 'double': 'd'}[ret.replace('const', '').strip()]
+        assert kinds.get(restype, 'v' if restype is None else 'p') == rk, f'{name}: return type'
+
+
+def test_ctypes_structs_match_the_header():
+    """Field names, order and types of cat_conv_t / cat_norm_t against their ctypes mirrors."""
+    import ctypes as C
+    text = open(os.path.join(ROOT, 'include', 'cat_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    for cname, cls in (('cat_conv_t', _lib.ConvGeom), ('cat_norm_t', _lib.NormGeom)):
+        body = re.search(r'typedef struct\s*(?:\w+\s*)?\{([^}]*)\}\s*' + cname + r'\s*;', text).group(1)
+        fields = []
+        for decl in body.split(';'):
+            decl = decl.strip()
+            if decl:
+                ctype, names = decl.split(None, 1)
+                fields += [(n.strip(), {'int': C.c_int, 'float': C.c_float}[ctype]) for n in names.split(',')]
+        assert fields == list(cls._fields_), cname
