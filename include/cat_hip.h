@@ -60,8 +60,9 @@ size_t cat_conv2d_wgrad_ws_bytes(const cat_conv_t* g);
 int cat_conv2d_wgrad(const cat_conv_t* g, const float* x, const float* dy, float* dw, int accumulate, void* ws,
                      cat_stream_t stream);
 /* Split-K variants for layers whose output tile grid cannot fill 256 CUs (few pixels, very deep reduction: the 4x8 .. 32x64
- * blocks of the SPADE generators, inception_spade_generator.py:63-124).  *_ws_bytes returns 0 when the plain entry point is
- * the right one; otherwise the caller provides that much scratch and the library reduces the K slices (+ bias, activation). */
+ * blocks of the SPADE generators, inception_spade_generator.py:63-124; PatchGAN's 1024 -> 1 head, discriminators.py:72-74, whose
+ * input channels are cut into slices).  *_ws_bytes returns 0 when the plain entry point is the right one; otherwise the caller
+ * provides that much scratch and the library reduces the K slices (+ bias, activation). */
 size_t cat_conv2d_fwd_ws_bytes(const cat_conv_t* g);
 int cat_conv2d_fwd_ws(const cat_conv_t* g, const float* x, const float* w, const float* bias, float* y, void* ws,
                       cat_stream_t stream);
