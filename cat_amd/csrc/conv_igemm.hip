@@ -1261,7 +1261,7 @@ size_t cat_conv2d_fwd_ws_bytes(const cat_conv_t* g) {
     const int ks = cat::smallco_fwd_ksplit(g);
     return ks > 1 ? (size_t)ks * a.M * g->ycs * sizeof(float) : 0;
   }
-  if (!fwd_bk32_ok(a)) return 0;
+  if (cat::conv_tile_applicable(g) || !fwd_bk32_ok(a)) return 0;
   const SplitPlan sp = split_plan(a.M, a.Cout, (a.K + 31) >> 5);
   return sp.ksplit > 1 ? (size_t)sp.ksplit * a.M * g->ycs * sizeof(float) : 0;
 }
@@ -1297,6 +1297,10 @@ static int conv_fwd_impl(const cat_conv_t* g, const float* x, const float* w, co
     return 0;
   }
   const double prof_flops = 2.0 * (double)g->N * g->Ho * g->Wo * g->Cout * g->kh * g->kw * g->Cin;
+  if (cat::conv_tile_applicable(g)) {
+    cat::ProfScope prof("conv_fwd_tile", prof_flops, 0.0, stream);
+    return cat::conv_tile_fwd(g, x, w, bias, y, s);
+  }
   static const int sched = getenv("CAT_SCHED") ? atoi(getenv("CAT_SCHED")) : 0;
   static const int lds_pad = getenv("CAT_LDS_PAD") ? atoi(getenv("CAT_LDS_PAD")) : 0;  // diagnostics: caps workgroups/CU
   static long long* dbg_buf = nullptr;

@@ -1,0 +1,88 @@
+"""GPU check of the opt-in LDS-tile conv kernel (conv_tile.hip) against ATen on the host; run with CAT_CONV_TILE=2 (force).
+Exits non-zero on a mismatch or if the tile kernel was not the one that ran.  Also prints its time next to the im2col kernel's
+on the layers it is meant for when called with --bench (two processes: CAT_CONV_TILE=0 / 1)."""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+from cat_amd import _lib as L, ops, synthetic  # noqa: E402
+
+CASES = [  # cin, cout, k, reflect, act, n, h, w
+    (54, 7, 5, True, 0, 2, 16, 16), (96, 16, 3, True, 1, 1, 6, 6), (22, 18, 5, True, 0, 1, 9, 35), (10, 7, 3, False, 2, 2, 8, 32),
+    (36, 42, 5, False, 1, 1, 11, 40), (16, 16, 3, True, 0, 1, 16, 33), (82, 17, 5, True, 1, 2, 24, 40), (256, 42, 3, True, 1, 1, 16, 64),
+    (4, 1, 3, False, 0, 1, 5, 5), (77, 33, 5, False, 3, 1, 8, 8),
+]
+
+
+def families():
+    lib = L.load()
+    n = lib.cat_prof_collect()
+    name, cnt, ms, fl = C.create_string_buffer(64), C.c_int64(), C.c_double(), C.c_double()
+    out = {}
+    for i in range(n):
+        lib.cat_prof_family(i, name, 64, C.byref(cnt), C.byref(ms), C.byref(fl))
+        out[name.value.decode()] = (cnt.value, ms.value, fl.value)
+    return out
+
+
+def main():
+    lib = L.load()
+    dev = torch.device('cuda:0')
+    if '--bench' in sys.argv:
+        shapes = [('S 82->17 k5 @64', 82, 17, 5, 16, 64, 64), ('S 82->17 k3 @64', 82, 17, 3, 16, 64, 64), ('S 82->14 k5 @64', 82, 14, 5, 16, 64, 64),
+                  ('T 256->42 k5 @64', 256, 42, 5, 16, 64, 64), ('T 256->42 k3 @64', 256, 42, 3, 16, 64, 64)]
+        for name, cin, cout, k, n, h, w in shapes:
+            x = ops.to_nhwc(torch.randn(n, cin, h, w, device=dev))
+            wt = ops.padded_weight_like((cout, cin, k, k), dev)
+            wt.copy_(torch.randn(cout, cin, k, k, device=dev))
+            fn = lambda: ops.Conv2dFn.apply(x, wt, None, 1, (k - 1) // 2, L.PAD_REFLECT, L.ACT_RELU, 0.0)
+            with torch.no_grad():
+                for _ in range(3):
+                    fn()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(20):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 50
+            print(f'{name:20s} {us:9.1f} us  {2.0 * n * h * w * cout * k * k * cin / us / 1e6:7.2f} TFLOP/s  (CAT_CONV_TILE={os.environ.get("CAT_CONV_TILE", "0")})')
+        return 0
+    lib.cat_prof_enable(1)
+    worst = 0.0
+    for cin, cout, k, reflect, act, n, h, w in CASES:
+        pad = (k - 1) // 2
+        x = synthetic.normal((n, cin, h, w), 1)
+        wt = synthetic.normal((cout, cin, k, k), 2, 1.0 / np.sqrt(cin * k * k))
+        b = synthetic.normal((cout,), 3, 0.1)
+        xp = F.pad(x, (pad,) * 4, mode='reflect') if reflect else x
+        yr = F.conv2d(xp, wt, b, padding=0 if reflect else pad)
+        yr = {0: yr, 1: F.relu(yr), 2: F.leaky_relu(yr, 0.2), 3: torch.tanh(yr)}[act]
+        wg = ops.padded_weight_like((cout, cin, k, k), dev)      # the product's parameter layout: [O][kh][kw][round_up(I, 4)]
+        wg.copy_(wt)
+        with torch.no_grad():
+            y = ops.Conv2dFn.apply(ops.to_nhwc(x.to(dev)), wg, b.to(dev), 1, pad, 1 if reflect else 0, act, 0.2)
+        err = float((y.cpu() - yr).abs().max() / yr.abs().max())
+        cs = ops.act_cs(y)
+        full = torch.as_strided(y, (y.shape[0], cs, y.shape[2], y.shape[3]), y.stride())
+        padz = float(full[:, cout:].abs().max()) if cs > cout else 0.0
+        print(f'{cin}->{cout} k{k} reflect={reflect} act={act} {n}x{h}x{w}: rel err {err:.2e}, pad lanes {padz}')
+        worst = max(worst, err, padz)
+    torch.cuda.synchronize()
+    fam = families()
+    lib.cat_prof_enable(0)
+    used = fam.get('conv_fwd_tile', (0, 0, 0))[0]
+    print('conv_fwd_tile launches:', used, '| other conv families:', sorted(k for k in fam if k.startswith('conv_') and k != 'conv_fwd_tile'))
+    ok = worst < 1e-4 and used == len(CASES)
+    print('OK' if ok else 'FAILED')
+    return 0 if ok else 1
+
+
+if __name__ == '__main__':
+    sys.exit(main())
