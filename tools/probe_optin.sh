@@ -1,0 +1,18 @@
+#!/bin/bash
+# First GPU call of a session: validate and A/B every opt-in kernel switch in one go (summaries under gpurun_out/probe/).
+#   gpurun --timeout 420 -- 'bash tools/probe_optin.sh'
+set -u
+out=gpurun_out/probe
+mkdir -p $out
+# 1. opt-in kernels against ATen (own processes: the library reads its switches once)
+CAT_EXPERIMENTAL=1 timeout 200 python -m pytest tests/test_experimental_gpu.py -q --tb=short 2>&1 | tail -15 > $out/experimental_tests.txt
+# 2. LDS-tile conv vs the im2col kernel on the layers it targets
+for v in 0 1; do CAT_CONV_TILE=$v timeout 60 python tools/debug/check_conv_tile.py --bench 2>&1 | grep -v amdgpu.ids; done > $out/conv_tile_bench.txt
+# 3. whole step + student forward with the switch on (no CPU leg, short)
+for v in 0 1; do
+  CAT_CONV_TILE=$v timeout 120 python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null |
+    python -c "import json,sys; d=json.loads(sys.stdin.readline()); print('CAT_CONV_TILE=$v', d['value'], 'img/s', d['ms_per_step'], 'ms; student fwd', d['student_forward']['ms'], 'ms', d['student_forward']['tflops'], 'TF')"
+done > $out/bench_ab.txt 2>&1
+# 4. wgrad pixel-split plan on the student's layers
+timeout 60 python tools/debug/wgrad_blocks.py 2>&1 | grep -v amdgpu.ids > $out/wgrad_blocks.txt
+tail -n +1 $out/*.txt
