@@ -1430,6 +1430,10 @@ static int conv_dgrad_impl(const cat_conv_t* g, const float* dy, const float* w,
                                                                             a.slope);      \
     }                                                                                      \
   }
+  if (a.ksplit == 1 && cat::conv_tile_dgrad_applicable(g, dxcw)) {
+    cat::ProfScope prof("conv_dgrad_tile", prof_flops, 0.0, stream);
+    return cat::conv_tile_dgrad(g, dy, w, bias, dx, dxcs, dxcw, s);
+  }
   // BK = 32 variant of the 128 x 128 tile (the discriminator's and the teacher's wide layers)
   static const int bk32 = getenv("CAT_DGRAD_BK32") ? atoi(getenv("CAT_DGRAD_BK32")) : 1;
   if (bk32 && a.ksplit == 1 && a.Cin > 96 && a.wvec && g->Cout % 16 == 0 && g->Cin % 4 == 0) {

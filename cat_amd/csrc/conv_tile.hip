@@ -1,4 +1,4 @@
-// LDS-tile forward convolution for narrow outputs (Cout <= 48), stride 1, "same" 3x3 / 5x5, NHWC, gfx950.
+// LDS-tile convolution for narrow outputs (GEMM-N <= 48), stride 1, 3x3 / 5x5, NHWC, gfx950: forward ("same" padding) and dgrad.
 //
 // OPT-IN (CAT_CONV_TILE=1) until it has been validated and timed on hardware: written at the end of round 1 without GPU time left;
 // tools/debug/emulate_conv_tile.py replays its staging / fragment indexing in numpy against a direct convolution.
@@ -10,25 +10,33 @@
 // ds_read_b128 at a compile-time offset from a per-lane base (pixel pitch 20 floats: the 16 lanes of a quarter wave hit 16 disjoint
 // 4-bank groups), feeding 4 v_mfma_f32_16x16x4_f32 per 16 output channels.  B fragments ([co][tap][ci] filter rows, 64 B per output
 // channel and tap) come straight from L1/L2, prefetched one tap ahead.  K order = channel chunk outer, taps inner.
-//   workgroup: 256 threads = 4 waves; wave w owns output rows 2w, 2w+1 of the tile = 4 M-tiles of 16 pixels; NT = ceil(Cout / 16).
+//   workgroup: 256 threads = 4 waves; wave w owns output rows 2w, 2w+1 of the tile = 4 M-tiles of 16 pixels; NT = ceil(N / 16).
+// One kernel body, two operand conventions (out[oy][ox][n] = sum_{ky,kx,c} in[oy - padv + ky][ox - padv + kx][c] * B(tap, c, n)):
+//   forward : in = x (c = input channel), n = output channel, B = w[n][tap][c] (a float4 of c per lane), padv = pad, zero / reflect
+//   dgrad   : in = dy (c = OUTPUT channel of the forward conv), n = input channel, B = w[c][TAPS-1-tap][n] (four scalars per lane,
+//             c-stride TAPS*wcs), padv = k - 1 - pad_eff, zero padding only; the output plane is x's (zero pad) or the padded plane
+//             of a reflect-padded conv (pad_eff = 0: the caller folds the border back, as for conv_dgrad_kernel).
 #include "common.h"
 #include <stdlib.h>
 
 namespace cat_tile {
 
 struct Args {
-  const float* x; const float* w; const float* bias; float* y;
-  int N, H, W, Cin, xcs, Cout, ycs, pad, reflect, act;
+  const float* x; const float* w; const float* bias; float* y;   // x = staged operand (x or dy), y = output (y or dx)
+  int N, H, W, xcs;        // staged tensor: plane size, pixel stride
+  int Ho, Wo, ycs;         // output plane, pixel stride
+  int Ck, Nn;              // reduction channels (valid), output channels (valid)
+  int pad, reflect, act;   // pad = padv of the header comment
   float slope;
-  int cw, c4, wcs, tiles_x, tiles_y;
+  int cw, c4, wcs, tiles_x, tiles_y;   // c4 = round_up(Ck, 4)
 };
 
 __device__ __attribute__((aligned(16))) float g_zero[4] = {0.f, 0.f, 0.f, 0.f};
 
 constexpr int TH = 8, TW = 32, PITCH = 20, CK = 16;
 
-template <int KS, int NT>
-__global__ __launch_bounds__(256) void fwd_kernel(Args p) {
+template <int KS, int NT, bool DGRAD>
+__global__ __launch_bounds__(256) void tile_kernel(Args p) {
   constexpr int TR = TH + KS - 1, TC = TW + KS - 1, TAPS = KS * KS;
   constexpr int SLOTS = TR * TC * 4;              // float4 per staged chunk
   constexpr int ITERS = (SLOTS + 255) / 256;
@@ -75,14 +83,17 @@ __global__ __launch_bounds__(256) void fwd_kernel(Args p) {
     }
   };
 
-  // B rows of this lane: output channel j*16 + lr, channel quad lq of the chunk
+  // B operand of this lane: output channel n = j*16 + lr, reduction channels c0 + lq*4 .. +3 of the chunk
+  //   forward: one float4 at w[n][tap][c0 + lq*4];  dgrad: four scalars w[c0 + lq*4 + t][TAPS-1-tap][n]
+  constexpr int BE = DGRAD ? 4 : 1;
   const float* brow[NT];
   bool bval[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
-    const int co = j * 16 + lr;
-    bval[j] = co < p.Cout;
-    brow[j] = p.w + (int64_t)(bval[j] ? co : 0) * TAPS * p.wcs + lq * 4;
+    const int nn = j * 16 + lr;
+    bval[j] = nn < p.Nn;
+    if (DGRAD) brow[j] = p.w + ((int64_t)(lq * 4) * TAPS + (TAPS - 1)) * p.wcs + (bval[j] ? nn : 0);
+    else brow[j] = p.w + (int64_t)(bval[j] ? nn : 0) * TAPS * p.wcs + lq * 4;
   }
 
   f4 acc[4][NT];
@@ -100,25 +111,45 @@ __global__ __launch_bounds__(256) void fwd_kernel(Args p) {
     sstore();
     __syncthreads();
     if (ch + 1 < nch) gload(c0 + CK);   // in flight behind this chunk's MFMA stream
-    const float* pb[NT];
-    int incb[NT];
+    const float* pb[NT][BE];
+    int incb[NT][BE];
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-      const bool v = bval[j] && c0 + lq * 4 < p.c4;
-      pb[j] = v ? brow[j] + c0 : g_zero;
-      incb[j] = v ? p.wcs : 0;
+#pragma unroll
+      for (int e = 0; e < BE; ++e) {
+        if (DGRAD) {   // rows c >= Ck do not exist in w: per-element validity (only the last quad of the last chunk is ragged)
+          const bool v = bval[j] && c0 + lq * 4 + e < p.Ck;
+          pb[j][e] = v ? brow[j] + (int64_t)(c0 + e) * TAPS * p.wcs : g_zero;
+          incb[j][e] = v ? -p.wcs : 0;
+        } else {
+          const bool v = bval[j] && c0 + lq * 4 < p.c4;
+          pb[j][e] = v ? brow[j] + c0 : g_zero;
+          incb[j][e] = v ? p.wcs : 0;
+        }
+      }
     }
+    auto bload = [&](int j) {
+      f4 v;
+      if (DGRAD) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = *pb[j][e];
+      } else {
+        v = *reinterpret_cast<const f4*>(pb[j][0]);
+      }
+      return v;
+    };
     f4 fb[NT], fbn[NT];
 #pragma unroll
-    for (int j = 0; j < NT; ++j) fb[j] = *reinterpret_cast<const f4*>(pb[j]);
+    for (int j = 0; j < NT; ++j) fb[j] = bload(j);
 #pragma unroll
     for (int tap = 0; tap < TAPS; ++tap) {
       const int ky = tap / KS, kx = tap % KS;
       if (tap + 1 < TAPS) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-          pb[j] += incb[j];
-          fbn[j] = *reinterpret_cast<const f4*>(pb[j]);
+#pragma unroll
+          for (int e = 0; e < BE; ++e) pb[j][e] += incb[j][e];
+          fbn[j] = bload(j);
         }
       }
       f4 fa[4];
@@ -140,16 +171,16 @@ __global__ __launch_bounds__(256) void fwd_kernel(Args p) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int oy = oy0 + 2 * wave + (i >> 1);
-    if (oy >= p.H) continue;
+    if (oy >= p.Ho) continue;
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) {
       const int ox = ox0 + (i & 1) * 16 + lq * 4 + rg;
-      if (ox >= p.W) continue;
-      float* yo = p.y + (((int64_t)n * p.H + oy) * p.W + ox) * p.ycs;
+      if (ox >= p.Wo) continue;
+      float* yo = p.y + (((int64_t)n * p.Ho + oy) * p.Wo + ox) * p.ycs;
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const int co = j * 16 + lr;
-        if (co < p.Cout) yo[co] = cat::apply_act(acc[i][j][rg] + (p.bias ? p.bias[co] : 0.f), p.act, p.slope);
+        if (co < p.Nn) yo[co] = cat::apply_act(acc[i][j][rg] + (p.bias ? p.bias[co] : 0.f), p.act, p.slope);
         else if (co < p.cw) yo[co] = 0.f;
       }
     }
@@ -160,37 +191,75 @@ __global__ __launch_bounds__(256) void fwd_kernel(Args p) {
 
 namespace cat {
 
-bool conv_tile_applicable(const cat_conv_t* g) {
-  static const int on = getenv("CAT_CONV_TILE") ? atoi(getenv("CAT_CONV_TILE")) : 0;
+static int tile_switch() {
+  static const int on = getenv("CAT_CONV_TILE") ? atoi(getenv("CAT_CONV_TILE")) : 0;   // 0 off, 1 on, 2 on for any size (tests)
+  return on;
+}
+
+static bool tile_geometry_ok(const cat_conv_t* g, int nn, int cw, int64_t out_pixels_h, int64_t out_pixels_w, int64_t staged_elems) {
+  const int on = tile_switch();
   if (!on) return false;
+  const int nt = cdiv(nn, 16);
+  return g->stride == 1 && g->kh == g->kw && (g->kh == 3 || g->kh == 5) && g->pad == (g->kh - 1) / 2 && nn <= 48 && cw <= nt * 16 &&
+         (on >= 2 || (int64_t)g->N * cdiv(out_pixels_h, cat_tile::TH) * cdiv(out_pixels_w, cat_tile::TW) >= 128) &&
+         staged_elems < (int64_t)4294967295LL;
+}
+
+bool conv_tile_applicable(const cat_conv_t* g) {
   const int wcs = g->wcs > 0 ? g->wcs : g->Cin;
   const int cw = g->ycw > g->Cout ? g->ycw : g->Cout;
-  const int nt = cdiv(g->Cout, 16);
-  return g->stride == 1 && g->kh == g->kw && (g->kh == 3 || g->kh == 5) && g->pad == (g->kh - 1) / 2 && g->Cout <= 48 && cw <= nt * 16 &&
-         (wcs & 3) == 0 && (on >= 2 || (int64_t)g->N * cdiv(g->H, cat_tile::TH) * cdiv(g->W, cat_tile::TW) >= 128) &&   // 2: force (tests)
-         (int64_t)g->N * g->H * g->W * g->xcs < (int64_t)4294967295LL;
+  return (wcs & 3) == 0 && tile_geometry_ok(g, g->Cout, cw, g->H, g->W, (int64_t)g->N * g->H * g->W * g->xcs);
+}
+
+// dgrad: GEMM-N = Cin; the output plane is x's (zero padding) or the reflect-padded plane (the caller folds it)
+bool conv_tile_dgrad_applicable(const cat_conv_t* g, int dxcw) {
+  const bool refl = g->pad_mode == CAT_PAD_REFLECT;
+  const int hin = refl ? g->H + 2 * g->pad : g->H, win = refl ? g->W + 2 * g->pad : g->W;
+  const int cw = dxcw > g->Cin ? dxcw : g->Cin;
+  return g->Cin <= 32 && tile_geometry_ok(g, g->Cin, cw, hin, win, (int64_t)g->N * g->Ho * g->Wo * g->ycs);   // N-tiles: 1 or 2 (registers)
+}
+
+template <bool DGRAD>
+static void tile_launch(const cat_tile::Args& a, int ks, int nt, dim3 grid, hipStream_t s) {
+#define CAT_TILE_LAUNCH(KS, NT) cat_tile::tile_kernel<KS, NT, DGRAD><<<grid, 256, 0, s>>>(a)
+  if (ks == 3) {
+    if (nt == 1) CAT_TILE_LAUNCH(3, 1); else if (nt == 2) CAT_TILE_LAUNCH(3, 2); else if constexpr (!DGRAD) CAT_TILE_LAUNCH(3, 3);
+  } else {
+    if (nt == 1) CAT_TILE_LAUNCH(5, 1); else if (nt == 2) CAT_TILE_LAUNCH(5, 2); else if constexpr (!DGRAD) CAT_TILE_LAUNCH(5, 3);
+  }
+#undef CAT_TILE_LAUNCH
 }
 
 int conv_tile_fwd(const cat_conv_t* g, const float* x, const float* w, const float* bias, float* y, hipStream_t s) {
   cat_tile::Args a{};
   a.x = x; a.w = w; a.bias = bias; a.y = y;
-  a.N = g->N; a.H = g->H; a.W = g->W; a.Cin = g->Cin; a.xcs = g->xcs; a.Cout = g->Cout; a.ycs = g->ycs;
+  a.N = g->N; a.H = g->H; a.W = g->W; a.xcs = g->xcs; a.Ho = g->H; a.Wo = g->W; a.ycs = g->ycs;
+  a.Ck = g->Cin; a.Nn = g->Cout;
   a.pad = g->pad; a.reflect = g->pad_mode == CAT_PAD_REFLECT; a.act = g->act; a.slope = g->slope;
   a.cw = g->ycw > g->Cout ? g->ycw : g->Cout;
   a.c4 = (g->Cin + 3) & ~3;
   a.wcs = g->wcs > 0 ? g->wcs : g->Cin;
-  a.tiles_x = cdiv(g->W, cat_tile::TW);
-  a.tiles_y = cdiv(g->H, cat_tile::TH);
-  const dim3 grid(a.tiles_x * a.tiles_y, g->N);
-  const int nt = cdiv(g->Cout, 16);
-#define CAT_TILE_LAUNCH(KS, NT) cat_tile::fwd_kernel<KS, NT><<<grid, 256, 0, s>>>(a)
-  if (g->kh == 3) {
-    if (nt == 1) CAT_TILE_LAUNCH(3, 1); else if (nt == 2) CAT_TILE_LAUNCH(3, 2); else CAT_TILE_LAUNCH(3, 3);
-  } else {
-    if (nt == 1) CAT_TILE_LAUNCH(5, 1); else if (nt == 2) CAT_TILE_LAUNCH(5, 2); else CAT_TILE_LAUNCH(5, 3);
-  }
-#undef CAT_TILE_LAUNCH
+  a.tiles_x = cdiv(a.Wo, cat_tile::TW);
+  a.tiles_y = cdiv(a.Ho, cat_tile::TH);
+  tile_launch<false>(a, g->kh, cdiv(g->Cout, 16), dim3(a.tiles_x * a.tiles_y, g->N), s);
   return check_launch("conv2d_fwd_tile");
+}
+
+int conv_tile_dgrad(const cat_conv_t* g, const float* dy, const float* w, const float* bias, float* dx, int dxcs, int dxcw, hipStream_t s) {
+  const bool refl = g->pad_mode == CAT_PAD_REFLECT;
+  cat_tile::Args a{};
+  a.x = dy; a.w = w; a.bias = bias; a.y = dx;
+  a.N = g->N; a.H = g->Ho; a.W = g->Wo; a.xcs = g->ycs;
+  a.Ho = refl ? g->H + 2 * g->pad : g->H; a.Wo = refl ? g->W + 2 * g->pad : g->W; a.ycs = dxcs;
+  a.Ck = g->Cout; a.Nn = g->Cin;
+  a.pad = g->kh - 1 - (refl ? 0 : g->pad); a.reflect = 0; a.act = g->act; a.slope = g->slope;
+  a.cw = dxcw > g->Cin ? dxcw : g->Cin;
+  a.c4 = (g->Cout + 3) & ~3;
+  a.wcs = g->wcs > 0 ? g->wcs : g->Cin;
+  a.tiles_x = cdiv(a.Wo, cat_tile::TW);
+  a.tiles_y = cdiv(a.Ho, cat_tile::TH);
+  tile_launch<true>(a, g->kh, cdiv(g->Cin, 16), dim3(a.tiles_x * a.tiles_y, g->N), s);
+  return check_launch("conv2d_dgrad_tile");
 }
 
 }  // namespace cat

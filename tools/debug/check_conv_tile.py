@@ -20,6 +20,11 @@ CASES = [  # cin, cout, k, reflect, act, n, h, w
 ]
 
 
+DGRAD_CASES = [  # cin, cout, k, reflect, n, h, w   (forward of these runs on the im2col kernel: Cout > 48)
+    (18, 82, 5, True, 1, 9, 33), (12, 54, 3, False, 2, 8, 20), (17, 50, 5, False, 1, 10, 34), (32, 56, 3, True, 1, 16, 40),
+]
+
+
 def families():
     lib = L.load()
     n = lib.cat_prof_collect()
@@ -53,6 +58,25 @@ def main():
                 torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 50
             print(f'{name:20s} {us:9.1f} us  {2.0 * n * h * w * cout * k * k * cin / us / 1e6:7.2f} TFLOP/s  (CAT_CONV_TILE={os.environ.get("CAT_CONV_TILE", "0")})')
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        for name, cin, cout, k, n, h, w in [('S dgrad 17<-82 k5 @64', 17, 82, 5, 16, 64, 64), ('S dgrad 17<-82 k3 @64', 17, 82, 3, 16, 64, 64)]:
+            p = (k - 1) // 2
+            dy = ops.to_nhwc(torch.randn(n, cout, h, w, device=dev))
+            wt = ops.padded_weight_like((cout, cin, k, k), dev)
+            wt.copy_(torch.randn(cout, cin, k, k, device=dev))
+            dx = ops.empty_act(n, cin, h + 2 * p, w + 2 * p, dev)
+            g = L.ConvGeom(n, h, w, cin, ops.cs_for(cin), h, w, cout, ops.act_cs(dy), k, k, 1, p, L.PAD_REFLECT, 0, 0.0, ops.act_cs(dy), ops.weight_wcs(wt))
+            fn = lambda: ops._conv_dgrad(g, dy, wt, None, dx, ops.act_cs(dx), ops.act_cs(dx), st)
+            for _ in range(3):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 50
+            print(f'{name:20s} {us:9.1f} us  {2.0 * n * h * w * cout * k * k * cin / us / 1e6:7.2f} TFLOP/s  (CAT_CONV_TILE={os.environ.get("CAT_CONV_TILE", "0")})')
         return 0
     lib.cat_prof_enable(1)
     worst = 0.0
@@ -74,12 +98,31 @@ def main():
         padz = float(full[:, cout:].abs().max()) if cs > cout else 0.0
         print(f'{cin}->{cout} k{k} reflect={reflect} act={act} {n}x{h}x{w}: rel err {err:.2e}, pad lanes {padz}')
         worst = max(worst, err, padz)
+    # dgrad convention: gradient w.r.t. the input of convs with few INPUT channels (GEMM-N = Cin <= 32)
+    for cin, cout, k, reflect, n, h, w in DGRAD_CASES:
+        pad = (k - 1) // 2
+        x = synthetic.normal((n, cin, h, w), 5)
+        wt = synthetic.normal((cout, cin, k, k), 6, 1.0 / np.sqrt(cin * k * k))
+        gy = synthetic.normal((n, cout, h, w), 7)
+        xr = x.clone().requires_grad_(True)
+        xp = F.pad(xr, (pad,) * 4, mode='reflect') if reflect else xr
+        F.conv2d(xp, wt, None, padding=0 if reflect else pad).backward(gy)
+        wg = ops.padded_weight_like((cout, cin, k, k), dev)
+        wg.copy_(wt)
+        xg = ops.to_nhwc(x.to(dev)).detach().requires_grad_(True)
+        y = ops.Conv2dFn.apply(xg, wg, None, 1, pad, 1 if reflect else 0, 0, 0.0)
+        y.backward(ops.to_nhwc(gy.to(dev)))
+        err = float((xg.grad.cpu() - xr.grad).abs().max() / xr.grad.abs().max())
+        print(f'dgrad {cin}<-{cout} k{k} reflect={reflect} {n}x{h}x{w}: rel err {err:.2e}')
+        worst = max(worst, err)
     torch.cuda.synchronize()
     fam = families()
     lib.cat_prof_enable(0)
     used = fam.get('conv_fwd_tile', (0, 0, 0))[0]
-    print('conv_fwd_tile launches:', used, '| other conv families:', sorted(k for k in fam if k.startswith('conv_') and k != 'conv_fwd_tile'))
-    ok = worst < 1e-4 and used == len(CASES)
+    used_d = fam.get('conv_dgrad_tile', (0, 0, 0))[0]
+    print('conv_fwd_tile launches:', used, 'conv_dgrad_tile launches:', used_d, '| other conv families:',
+          sorted(k for k in fam if k.startswith('conv_') and k not in ('conv_fwd_tile', 'conv_dgrad_tile')))
+    ok = worst < 1e-4 and used == len(CASES) and used_d == len(DGRAD_CASES)
     print('OK' if ok else 'FAILED')
     return 0 if ok else 1
 
