@@ -288,9 +288,21 @@ class BaseInceptionDistiller:
         for i, optimizer in enumerate(self.optimizers):
             torch.save(optimizer.state_dict(), os.path.join(self.save_dir, '%s_optim-%d.pth' % (epoch, i)))
 
-    def evaluate_model(self, step):
-        raise NotImplementedError('FID / mIoU evaluation needs the reference\'s pretrained InceptionV3 / DRN weights and '
-                                  'datasets; it is outside the accelerated hot path (SURVEY §2 rows 18-19)')
+    def evaluate_model(self, step, save_image=False):
+        """reference inception_distiller.py:204-281: student (and teacher) inference over `self.eval_dataloader` on the HIP kernels, image
+        dumps, `is_best` / running-mean bookkeeping; the FID / mIoU networks themselves are the integrator's callables
+        `self.fid_fn(fakes)`, `self.miou_fn(fakes, names)` (cat_amd/distillers/evaluation.py, INTEGRATION.md)."""
+        from . import evaluation as E
+        aligned = self.opt.dataset_mode == 'aligned'
+
+        def images(j):
+            out = {'input': E.tensor2im(self.real_A[j]), 'Sfake': E.tensor2im(self.Sfake_B[j]), 'Tfake': E.tensor2im(self.Tfake_B[j])}
+            if aligned:
+                out['real'] = E.tensor2im(self.real_B[j])
+            return out
+        want_miou = 'cityscapes' in str(getattr(self.opt, 'dataroot', '')) and getattr(self.opt, 'direction', 'AtoB') == 'BtoA'
+        return E.evaluate(self, step, self.netG_student, self.set_input if aligned else self.set_single_input, images, True, want_miou,
+                          save_all=save_image)
 
     def test(self, teacher_forward=True):
         with torch.no_grad():

@@ -203,6 +203,14 @@ class BaseSPADEDistiller:
         for i, optimizer in enumerate(self.optimizers):
             torch.save(optimizer.state_dict(), os.path.join(self.save_dir, '%s_optim-%d.pth' % (epoch, i)))
 
-    def evaluate_model(self, step):
-        raise NotImplementedError('FID / mIoU evaluation needs the reference\'s pretrained InceptionV3 / DRN weights and datasets; it '
-                                  'is outside the accelerated hot path (SURVEY §2 rows 18-19)')
+    def evaluate_model(self, step, save_image=False):
+        """reference spade_distiller.py:96-180: see cat_amd/distillers/evaluation.py (generator passes here, metric networks attached by
+        the integrator as `self.fid_fn`, `self.miou_fn`)."""
+        from . import evaluation as E
+
+        def images(j):
+            return {'input': E.tensor2label(self.input_semantics[j], self.opt.input_nc + 2), 'real': E.tensor2im(self.real_B[j]),
+                    'Tfake': E.tensor2im(self.Tfake_B[j]), 'Sfake': E.tensor2im(self.Sfake_B[j])}
+        want_fid = not getattr(self.opt, 'no_fid', False)
+        want_miou = 'cityscapes' in str(getattr(self.opt, 'dataroot', '')) and not getattr(self.opt, 'no_mIoU', False)
+        return E.evaluate(self, step, self.modules_on_one_gpu.netG_student, self.set_input, images, want_fid, want_miou, save_all=save_image)

@@ -328,7 +328,25 @@ def weight_transfer_golden():
     print('weight_transfer.npz', len(sd), 'tensors')
 
 
+def eval_utils_golden():
+    """utils/util.py tensor2im / tensor2label / labelcolormap on seeded tensors: pins cat_amd/distillers/evaluation.py (image dumps of
+    evaluate_model)."""
+    from utils import util
+    img = torch.tanh(detfill.normal((3, 12, 10), 77) * 1.5)
+    img[0, 0, 0], img[1, 0, 1] = 1.0, -1.0
+    lab = torch.zeros(37, 6, 7)
+    idx = torch.from_numpy(np.random.default_rng(78).integers(0, 37, (6, 7)))
+    lab.scatter_(0, idx[None], 1.0)
+    out = {'img': img.numpy(), 'img_u8': util.tensor2im(img), 'gray_u8': util.tensor2im(img[:1]), 'lab': lab.numpy(),
+           'lab_u8': util.tensor2label(lab, 37), 'cmap37': util.labelcolormap(37), 'cmap20': util.labelcolormap(20)}
+    np.savez_compressed(os.path.join(OUT, 'eval_utils.npz'), **out)
+    print('eval_utils.npz', {k: v.shape for k, v in out.items()})
+
+
 if __name__ == '__main__':
+    if os.environ.get('GOLDEN_ONLY') == 'eval':
+        eval_utils_golden()
+        sys.exit(0)
     if os.environ.get('GOLDEN_ONLY') == 'transfer':
         weight_transfer_golden()
         sys.exit(0)
