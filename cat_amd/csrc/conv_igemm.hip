@@ -1097,6 +1097,13 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 }
 
 // ------------------------------------------------------------------------------------------------ host side
+// N = 130 .. 192 (the frozen teacher's 176-wide fused GEMM, SPADE's 170-wide heads) fills two 96-wide tiles better than two 128-wide
+// ones (8 % instead of 31 % padding at 176).  Opt-in (CAT_TILE_BY_PAD=1) until the two variants have been timed against each other.
+static bool prefer_96_wide(int n) {
+  static const int on = getenv("CAT_TILE_BY_PAD") ? atoi(getenv("CAT_TILE_BY_PAD")) : 0;
+  return on && n > 96 && (int64_t)cat::cdiv(n, 96) * 96 * 10 <= (int64_t)cat::cdiv(n, 128) * 128 * 9;
+}
+
 #define DISPATCH_TILE_N(n, LAUNCH)   \
   do {                               \
     if ((n) <= 16) {                 \
@@ -1107,7 +1114,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
       LAUNCH(2, 3, 4, 1);            \
     } else if ((n) <= 64) {          \
       LAUNCH(2, 4, 4, 1);            \
-    } else if ((n) <= 96) {          \
+    } else if ((n) <= 96 || prefer_96_wide(n)) { \
       LAUNCH(2, 6, 4, 1);            \
     } else {                         \
       LAUNCH(4, 4, 2, 2);            \

@@ -13,6 +13,9 @@ for v in 0 1; do
   CAT_CONV_TILE=$v timeout 120 python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null |
     python -c "import json,sys; d=json.loads(sys.stdin.readline()); print('CAT_CONV_TILE=$v', d['value'], 'img/s', d['ms_per_step'], 'ms; student fwd', d['student_forward']['ms'], 'ms', d['student_forward']['tflops'], 'TF')"
 done > $out/bench_ab.txt 2>&1
+# 3b. N-tile choice by padded-N cost (frozen teacher's 176-wide GEMM)
+CAT_TILE_BY_PAD=1 timeout 120 python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null |
+  python -c "import json,sys; d=json.loads(sys.stdin.readline()); print('CAT_TILE_BY_PAD=1', d['value'], 'img/s', d['ms_per_step'], 'ms')" >> $out/bench_ab.txt 2>&1
 # 4. wgrad pixel-split plan on the student's layers
 timeout 60 python tools/debug/wgrad_blocks.py 2>&1 | grep -v amdgpu.ids > $out/wgrad_blocks.txt
 tail -n +1 $out/*.txt
