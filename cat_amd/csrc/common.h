@@ -46,6 +46,10 @@ int conv_tile_fwd(const cat_conv_t* g, const float* x, const float* w, const flo
 bool conv_tile_dgrad_applicable(const cat_conv_t* g, int dxcw);
 int conv_tile_dgrad(const cat_conv_t* g, const float* dy, const float* w, const float* bias, float* dx, int dxcs, int dxcw, hipStream_t s);
 
+bool conv_tile_wgrad_applicable(const cat_conv_t* g);
+int conv_tile_wgrad_nsplit(const cat_conv_t* g);
+int conv_tile_wgrad(const cat_conv_t* g, const float* x, const float* dy, float* ws, hipStream_t s);   // partials [nsplit][Cout][taps*c4]
+
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 

@@ -1465,6 +1465,7 @@ size_t cat_conv2d_wgrad_ws_bytes(const cat_conv_t* g) {
   const WgradPlan pl = wgrad_plan(g);
   const size_t K = (size_t)g->kh * g->kw * ((g->Cin + 3) & ~3);
   if (cat::smallco_applicable(g)) return (size_t)cat::smallco_wgrad_nblk(g) * g->Cout * K * sizeof(float);
+  if (cat::conv_tile_wgrad_applicable(g)) return (size_t)cat::conv_tile_wgrad_nsplit(g) * g->Cout * K * sizeof(float);
   return (size_t)pl.nsplit * g->Cout * K * sizeof(float);
 }
 
@@ -1493,8 +1494,17 @@ int cat_conv2d_wgrad(const cat_conv_t* g, const float* x, const float* dy, float
                                                                   a.cval, a.wcs, a.c4, a.K, accumulate);
     return cat::check_launch("conv2d_wgrad_reduce");
   }
-  CAT_REQUIRE(a.direct || ws != nullptr, "conv wgrad: workspace required");
   const double prof_flops = 2.0 * (double)g->N * g->Ho * g->Wo * g->Cout * g->kh * g->kw * g->Cin;
+  if (cat::conv_tile_wgrad_applicable(g)) {
+    CAT_REQUIRE(ws != nullptr, "conv wgrad: workspace required");
+    cat::ProfScope prof("conv_wgrad_tile", prof_flops, 0.0, stream);
+    if (int e = cat::conv_tile_wgrad(g, x, dy, (float*)ws, s)) return e;
+    const int64_t total = (int64_t)a.Cout * a.kh * a.kw * a.cval;
+    wgrad_reduce_kernel<<<(int)((total + 63) / 64), 256, 0, s>>>((const float*)ws, dw, cat::conv_tile_wgrad_nsplit(g), a.Cout, a.kh * a.kw,
+                                                                  a.cval, a.wcs, a.c4, a.K, accumulate);
+    return cat::check_launch("conv2d_wgrad_reduce");
+  }
+  CAT_REQUIRE(a.direct || ws != nullptr, "conv wgrad: workspace required");
 #define LAUNCH(MT, NT, WM, WN)                                                                         \
   {                                                                                                    \
     cat::ProfScope prof("conv_wgrad_" #MT "x" #NT "x" #WM "x" #WN, prof_flops, 0.0, stream); \

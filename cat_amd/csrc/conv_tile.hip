@@ -263,3 +263,178 @@ int conv_tile_dgrad(const cat_conv_t* g, const float* dy, const float* w, const 
 }
 
 }  // namespace cat
+
+// ------------------------------------------------------------------------------------------------ wgrad from LDS tiles
+// dw[co][tap][ci] = sum_p dy[p][co] * x[p + tap][ci] for the narrow student layers, whose im2col wgrad spends more vector-ALU time
+// on the per-pixel gather than the matrix pipe spends on the product (77 -> 18, 5x5: 34 TFLOP/s).  Per workgroup: one pair of 16-wide
+// output-channel tiles x one 16-channel chunk of x x a strided subset of the 8 x 32 pixel tiles.  Both operands of a tile are staged in
+// LDS at a pixel pitch of exactly 16 floats -- an MFMA fragment (16 channels x 4 consecutive pixels) is then 64 consecutive floats,
+// read with one conflict-free ds_read_b32: A = dy[4 px][16 co], B = x[4 px shifted by the tap][16 ci], one v_mfma_f32_16x16x4_f32 per
+// (pixel group, tap, co tile).  The k*k taps are dealt round-robin to the four waves (accumulators: <= 7 taps x 2 co tiles), every wave
+// walks all 64 pixel groups of the tile.  Raw partial sums go to ws[z][co][tap*c4 + ci]; the shared wgrad_reduce_kernel finishes.
+namespace cat_tile {
+
+struct WArgs {
+  const float* x; const float* dy; float* part;
+  int N, H, W, xcs, ycs, Cin, Cout, pad, reflect;
+  int c4, K, tiles_x, tiles_y, ntiles;
+};
+
+template <int KS, int NCO>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void wgrad_tile_kernel(WArgs p) {
+  constexpr int TR = TH + KS - 1, TC = TW + KS - 1, TAPS = KS * KS;
+  constexpr int XSLOTS = TR * TC * 4, XITERS = (XSLOTS + 255) / 256;
+  constexpr int DSLOTS = TH * TW * 4 * NCO, DITERS = DSLOTS / 256;
+  constexpr int NSLOT = (TAPS + 3) / 4;   // taps per wave (round-robin)
+  __shared__ __attribute__((aligned(16))) float xt[TR * TC * 16];
+  __shared__ __attribute__((aligned(16))) float dyt[NCO * TH * TW * 16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lq = lane >> 4;
+  const int co0 = blockIdx.y * 16 * NCO, c0 = blockIdx.z * 16;
+  const int cout4 = (p.Cout + 3) & ~3;
+
+  f4 xreg[XITERS], dreg[DITERS];
+  auto gload = [&](int t) {
+    const int per = p.tiles_x * p.tiles_y;
+    const int n = t / per, tt = t - n * per;
+    const int oy0 = (tt / p.tiles_x) * TH, ox0 = (tt % p.tiles_x) * TW;
+#pragma unroll
+    for (int it = 0; it < XITERS; ++it) {
+      const int idx = tid + it * 256;
+      const int pix = idx >> 2, quad = idx & 3;
+      const int r = pix / TC, c = pix - r * TC;
+      int iy = oy0 - p.pad + r, ix = ox0 - p.pad + c;
+      bool v = idx < XSLOTS && c0 + quad * 4 < p.c4;
+      if (p.reflect) {
+        v = v && iy >= -p.pad && iy < p.H + p.pad && ix >= -p.pad && ix < p.W + p.pad;
+        iy = cat::reflect_idx(iy, p.H);
+        ix = cat::reflect_idx(ix, p.W);
+      } else {
+        v = v && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      }
+      xreg[it] = *reinterpret_cast<const f4*>(v ? p.x + (((int64_t)n * p.H + iy) * p.W + ix) * p.xcs + c0 + quad * 4 : g_zero);
+    }
+#pragma unroll
+    for (int it = 0; it < DITERS; ++it) {
+      const int idx = tid + it * 256;
+      const int pix = idx / (4 * NCO), quad = idx - pix * (4 * NCO);
+      const int oy = oy0 + pix / TW, ox = ox0 + pix % TW;
+      const bool v = oy < p.H && ox < p.W && co0 + quad * 4 < cout4;
+      dreg[it] = *reinterpret_cast<const f4*>(v ? p.dy + (((int64_t)n * p.H + oy) * p.W + ox) * p.ycs + co0 + quad * 4 : g_zero);
+    }
+  };
+  auto sstore = [&]() {
+#pragma unroll
+    for (int it = 0; it < XITERS; ++it) {
+      const int idx = tid + it * 256;
+      if (idx < XSLOTS) *reinterpret_cast<f4*>(xt + idx * 4) = xreg[it];           // [pixel][16]: slot idx = pixel * 4 + quad
+    }
+#pragma unroll
+    for (int it = 0; it < DITERS; ++it) {
+      const int idx = tid + it * 256;
+      const int pix = idx / (4 * NCO), quad = idx - pix * (4 * NCO);
+      *reinterpret_cast<f4*>(dyt + ((quad >> 2) * TH * TW + pix) * 16 + (quad & 3) * 4) = dreg[it];   // [co tile][pixel][16]
+    }
+  };
+
+  f4 acc[NSLOT][NCO];
+#pragma unroll
+  for (int s = 0; s < NSLOT; ++s)
+#pragma unroll
+    for (int j = 0; j < NCO; ++j) acc[s][j] = f4{0.f, 0.f, 0.f, 0.f};
+
+  static_assert(TAPS == 4 * (NSLOT - 1) + 1, "tap dealing assumes k*k = 1 (mod 4)");
+  int toff[NSLOT];   // LDS offset of the tap each accumulator slot of this wave owns
+#pragma unroll
+  for (int s = 0; s < NSLOT; ++s) {
+    const int tap = min(wave + 4 * s, TAPS - 1);
+    toff[s] = ((tap / KS) * TC + tap % KS) * 16;
+  }
+  int t = blockIdx.x;
+  if (t < p.ntiles) gload(t);
+  for (; t < p.ntiles; t += gridDim.x) {
+    __syncthreads();   // previous tile fully consumed
+    sstore();
+    __syncthreads();
+    if (t + (int)gridDim.x < p.ntiles) gload(t + gridDim.x);
+    for (int r = 0; r < TH; ++r) {
+#pragma unroll
+      for (int cg = 0; cg < TW / 4; ++cg) {
+        float a[NCO];
+#pragma unroll
+        for (int j = 0; j < NCO; ++j) a[j] = dyt[(j * TH * TW + r * TW + cg * 4 + lq) * 16 + lr];
+#pragma unroll
+        for (int s = 0; s < NSLOT; ++s) {
+          // taps wave, wave + 4, ...: k*k = 4 * (NSLOT - 1) + 1, so only the last slot is conditional (it exists for wave 0 alone)
+          if (s + 1 < NSLOT || wave == 0) {
+            const float b = xt[toff[s] + (r * TC + cg * 4 + lq) * 16 + lr];
+#pragma unroll
+            for (int j = 0; j < NCO; ++j) acc[s][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b, acc[s][j], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+
+  float* part = p.part + (int64_t)blockIdx.x * p.Cout * p.K;
+  const int ci = c0 + lr;
+#pragma unroll
+  for (int s = 0; s < NSLOT; ++s) {
+    const int tap = wave + 4 * s;
+    if (tap >= TAPS || ci >= p.c4) continue;
+#pragma unroll
+    for (int j = 0; j < NCO; ++j) {
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int co = co0 + j * 16 + lq * 4 + rg;
+        if (co < p.Cout) part[(int64_t)co * p.K + tap * p.c4 + ci] = acc[s][j][rg];
+      }
+    }
+  }
+}
+
+}  // namespace cat_tile
+
+namespace cat {
+
+bool conv_tile_wgrad_applicable(const cat_conv_t* g) {
+  const int on = tile_switch();
+  if (!on) return false;
+  const int lo = g->Cin < g->Cout ? g->Cin : g->Cout;
+  return g->stride == 1 && g->kh == g->kw && (g->kh == 3 || g->kh == 5) && g->pad == (g->kh - 1) / 2 && lo <= 32 && g->Cin <= 128 &&
+         g->Cout <= 128 && (on >= 2 || (int64_t)g->N * cdiv(g->H, cat_tile::TH) * cdiv(g->W, cat_tile::TW) >= 64);
+}
+
+// pixel-split count: enough workgroups for ~2 per CU, never more than there are tiles
+int conv_tile_wgrad_nsplit(const cat_conv_t* g) {
+  const int nco = g->Cout <= 16 ? 1 : 2;
+  const int groups = cdiv(g->Cout, 16 * nco) * cdiv((g->Cin + 3) & ~3, 16);
+  const int ntiles = g->N * cdiv(g->H, cat_tile::TH) * cdiv(g->W, cat_tile::TW);
+  int nz = cdiv(512, groups);
+  if (nz > ntiles) nz = ntiles;
+  if (nz > 256) nz = 256;
+  return nz < 1 ? 1 : nz;
+}
+
+// partial sums -> ws[nsplit][Cout][taps * c4]; the caller runs wgrad_reduce_kernel over them
+int conv_tile_wgrad(const cat_conv_t* g, const float* x, const float* dy, float* ws, hipStream_t s) {
+  cat_tile::WArgs a{};
+  a.x = x; a.dy = dy; a.part = ws;
+  a.N = g->N; a.H = g->H; a.W = g->W; a.xcs = g->xcs; a.ycs = g->ycs; a.Cin = g->Cin; a.Cout = g->Cout;
+  a.pad = g->pad; a.reflect = g->pad_mode == CAT_PAD_REFLECT;
+  a.c4 = (g->Cin + 3) & ~3;
+  a.K = g->kh * g->kw * a.c4;
+  a.tiles_x = cdiv(g->W, cat_tile::TW);
+  a.tiles_y = cdiv(g->H, cat_tile::TH);
+  a.ntiles = g->N * a.tiles_x * a.tiles_y;
+  const int nco = g->Cout <= 16 ? 1 : 2;
+  const dim3 grid(conv_tile_wgrad_nsplit(g), cdiv(g->Cout, 16 * nco), cdiv(a.c4, 16));
+  if (g->kh == 3) {
+    if (nco == 1) cat_tile::wgrad_tile_kernel<3, 1><<<grid, 256, 0, s>>>(a); else cat_tile::wgrad_tile_kernel<3, 2><<<grid, 256, 0, s>>>(a);
+  } else {
+    if (nco == 1) cat_tile::wgrad_tile_kernel<5, 1><<<grid, 256, 0, s>>>(a); else cat_tile::wgrad_tile_kernel<5, 2><<<grid, 256, 0, s>>>(a);
+  }
+  return check_launch("conv2d_wgrad_tile");
+}
+
+}  // namespace cat

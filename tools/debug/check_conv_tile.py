@@ -25,6 +25,11 @@ DGRAD_CASES = [  # cin, cout, k, reflect, n, h, w   (forward of these runs on th
 ]
 
 
+WGRAD_CASES = [  # cin, cout, k, reflect, n, h, w
+    (22, 18, 5, True, 1, 9, 35), (18, 40, 3, False, 2, 8, 40), (6, 7, 5, False, 1, 16, 32), (82, 17, 5, True, 2, 16, 40), (17, 82, 3, True, 1, 8, 64),
+]
+
+
 def families():
     lib = L.load()
     n = lib.cat_prof_collect()
@@ -59,6 +64,26 @@ def main():
             us = e0.elapsed_time(e1) * 50
             print(f'{name:20s} {us:9.1f} us  {2.0 * n * h * w * cout * k * k * cin / us / 1e6:7.2f} TFLOP/s  (CAT_CONV_TILE={os.environ.get("CAT_CONV_TILE", "0")})')
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        for name, cin, cout, k, n, h, w in [('S wgrad 82->17 k5 @64', 82, 17, 5, 16, 64, 64), ('S wgrad 82->17 k3 @64', 82, 17, 3, 16, 64, 64),
+                                            ('S wgrad 17->82 k5 @64', 17, 82, 5, 16, 64, 64), ('S wgrad 17->82 k3 @64', 17, 82, 3, 16, 64, 64)]:
+            p = (k - 1) // 2
+            x = ops.to_nhwc(torch.randn(n, cin, h, w, device=dev))
+            dy = ops.to_nhwc(torch.randn(n, cout, h, w, device=dev))
+            dw = ops.padded_weight_like((cout, cin, k, k), dev)
+            g = L.ConvGeom(n, h, w, cin, ops.act_cs(x), h, w, cout, ops.act_cs(dy), k, k, 1, p, L.PAD_REFLECT, 0, 0.0, ops.act_cs(dy), ops.weight_wcs(dw))
+            ws = torch.empty(max(L.query('cat_conv2d_wgrad_ws_bytes', C.byref(g)) // 4, 1), device=dev)
+            P = lambda t: C.c_void_p(t.data_ptr())
+            fn = lambda: L.call('cat_conv2d_wgrad', C.byref(g), P(x), P(dy), P(dw), 0, P(ws), st)
+            for _ in range(3):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 50
+            print(f'{name:20s} {us:9.1f} us  {2.0 * n * h * w * cout * k * k * cin / us / 1e6:7.2f} TFLOP/s  (CAT_CONV_TILE={os.environ.get("CAT_CONV_TILE", "0")})')
         for name, cin, cout, k, n, h, w in [('S dgrad 17<-82 k5 @64', 17, 82, 5, 16, 64, 64), ('S dgrad 17<-82 k3 @64', 17, 82, 3, 16, 64, 64)]:
             p = (k - 1) // 2
             dy = ops.to_nhwc(torch.randn(n, cout, h, w, device=dev))
@@ -115,14 +140,33 @@ def main():
         err = float((xg.grad.cpu() - xr.grad).abs().max() / xr.grad.abs().max())
         print(f'dgrad {cin}<-{cout} k{k} reflect={reflect} {n}x{h}x{w}: rel err {err:.2e}')
         worst = max(worst, err)
+    # wgrad from LDS tiles: layers that are narrow on one side
+    for cin, cout, k, reflect, n, h, w in WGRAD_CASES:
+        pad = (k - 1) // 2
+        x = synthetic.normal((n, cin, h, w), 8)
+        wt = synthetic.normal((cout, cin, k, k), 9, 1.0 / np.sqrt(cin * k * k))
+        gy = synthetic.normal((n, cout, h, w), 10)
+        wr = wt.clone().requires_grad_(True)
+        xp = F.pad(x, (pad,) * 4, mode='reflect') if reflect else x
+        F.conv2d(xp, wr, None, padding=0 if reflect else pad).backward(gy)
+        wg = ops.padded_weight_like((cout, cin, k, k), dev)
+        wg.copy_(wt)
+        wg.requires_grad_(True)
+        y = ops.Conv2dFn.apply(ops.to_nhwc(x.to(dev)), wg, None, 1, pad, 1 if reflect else 0, 0, 0.0)
+        y.backward(ops.to_nhwc(gy.to(dev)))
+        err = float((wg.grad.cpu() - wr.grad).abs().max() / wr.grad.abs().max())
+        print(f'wgrad {cin}->{cout} k{k} reflect={reflect} {n}x{h}x{w}: rel err {err:.2e}')
+        worst = max(worst, err)
     torch.cuda.synchronize()
     fam = families()
     lib.cat_prof_enable(0)
     used = fam.get('conv_fwd_tile', (0, 0, 0))[0]
     used_d = fam.get('conv_dgrad_tile', (0, 0, 0))[0]
-    print('conv_fwd_tile launches:', used, 'conv_dgrad_tile launches:', used_d, '| other conv families:',
-          sorted(k for k in fam if k.startswith('conv_') and k not in ('conv_fwd_tile', 'conv_dgrad_tile')))
-    ok = worst < 1e-4 and used == len(CASES) and used_d == len(DGRAD_CASES)
+    used_w = fam.get('conv_wgrad_tile', (0, 0, 0))[0]
+    print('conv_fwd_tile launches:', used, 'conv_dgrad_tile launches:', used_d, 'conv_wgrad_tile launches:', used_w, '| other conv families:',
+          sorted(k for k in fam if k.startswith('conv_') and k not in ('conv_fwd_tile', 'conv_dgrad_tile', 'conv_wgrad_tile')))
+    n_fwd = len(CASES) + sum(1 for c in WGRAD_CASES if c[1] <= 48)      # the wgrad cases' forward passes may use the tile kernel too
+    ok = worst < 1e-4 and used == n_fwd and used_d == len(DGRAD_CASES) and used_w == len(WGRAD_CASES)
     print('OK' if ok else 'FAILED')
     return 0 if ok else 1
 

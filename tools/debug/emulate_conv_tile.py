@@ -174,3 +174,112 @@ if __name__ == '__main__':
     run_dgrad(2, 8, 20, 12, 22, 3, False)
     run_dgrad(1, 10, 34, 17, 16, 5, False)
     print('ok')
+
+
+def run_wgrad(N, H, W, Cin, Cout, KS, reflect, nz, seed=0):
+    """cat_tile::wgrad_tile_kernel + the partial reduce, against a direct weight gradient."""
+    rng = np.random.default_rng(seed)
+    pad = (KS - 1) // 2
+    NCO = 1 if Cout <= 16 else 2
+    c4 = (Cin + 3) & ~3
+    xcs, ycs = c4, (Cout + 3) & ~3
+    cout4 = ycs
+    x = np.zeros((N, H, W, xcs)); x[..., :Cin] = rng.standard_normal((N, H, W, Cin))
+    dy = np.zeros((N, H, W, ycs)); dy[..., :Cout] = rng.standard_normal((N, H, W, Cout))
+    xp = np.pad(x, ((0, 0), (pad, pad), (pad, pad), (0, 0)), mode='reflect' if reflect else 'constant')
+    TAPS = KS * KS
+    K = TAPS * c4
+    ref = np.zeros((Cout, TAPS, c4))
+    for ky in range(KS):
+        for kx in range(KS):
+            ref[:, ky * KS + kx, :] = np.einsum('nhwo,nhwc->oc', dy[..., :Cout], xp[:, ky:ky + H, kx:kx + W, :])
+    TR, TC = TH + KS - 1, TW + KS - 1
+    XSLOTS = TR * TC * 4
+    XITERS = (XSLOTS + 255) // 256
+    DSLOTS = TH * TW * 4 * NCO
+    DITERS = DSLOTS // 256
+    NSLOT = (TAPS + 3) // 4
+    tiles_x, tiles_y = -(-W // TW), -(-H // TH)
+    ntiles = N * tiles_x * tiles_y
+    part = np.full((nz, Cout, K), np.nan)
+    xf, dyf = x.reshape(-1), dy.reshape(-1)
+    for bz in range(-(-c4 // 16)):
+        for by in range(-(-Cout // (16 * NCO))):
+            for bx in range(nz):
+                co0, c0 = by * 16 * NCO, bz * 16
+                acc = np.zeros((4, NSLOT, NCO, 16, 16))     # wave, slot, co tile, m = co, n = ci
+                for t in range(bx, ntiles, nz):
+                    per = tiles_x * tiles_y
+                    n, tt = divmod(t, per)
+                    oy0, ox0 = (tt // tiles_x) * TH, (tt % tiles_x) * TW
+                    xt = np.full(TR * TC * 16, np.nan)
+                    dyt = np.full(NCO * TH * TW * 16, np.nan)
+                    for tid in range(256):
+                        for it in range(XITERS):
+                            idx = tid + it * 256
+                            pix, quad = idx >> 2, idx & 3
+                            r, c = divmod(pix, TC)
+                            iy, ix = oy0 - pad + r, ox0 - pad + c
+                            v = idx < XSLOTS and c0 + quad * 4 < c4
+                            if reflect:
+                                v = v and -pad <= iy < H + pad and -pad <= ix < W + pad
+                                iy, ix = reflect_idx(iy, H), reflect_idx(ix, W)
+                            else:
+                                v = v and 0 <= iy < H and 0 <= ix < W
+                            o = ((n * H + iy) * W + ix) * xcs + c0 + quad * 4
+                            val = xf[o:o + 4] if v else np.zeros(4)
+                            if idx < XSLOTS:
+                                xt[idx * 4:idx * 4 + 4] = val
+                        for it in range(DITERS):
+                            idx = tid + it * 256
+                            pix, quad = divmod(idx, 4 * NCO)
+                            oy, ox = oy0 + pix // TW, ox0 + pix % TW
+                            v = oy < H and ox < W and co0 + quad * 4 < cout4
+                            o = ((n * H + oy) * W + ox) * ycs + co0 + quad * 4
+                            val = dyf[o:o + 4] if v else np.zeros(4)
+                            d = ((quad >> 2) * TH * TW + pix) * 16 + (quad & 3) * 4
+                            dyt[d:d + 4] = val
+                    for wave in range(4):
+                        for r in range(TH):
+                            for cg in range(TW // 4):
+                                A = np.zeros((NCO, 16, 4))      # [co tile][m = co (lr)][k = pixel (lq)]
+                                for j in range(NCO):
+                                    for lr in range(16):
+                                        for lq in range(4):
+                                            A[j, lr, lq] = dyt[(j * TH * TW + r * TW + cg * 4 + lq) * 16 + lr]
+                                for s in range(NSLOT):
+                                    if s + 1 < NSLOT or wave == 0:
+                                        tap = min(wave + 4 * s, TAPS - 1)
+                                        toff = ((tap // KS) * TC + tap % KS) * 16
+                                        B = np.zeros((4, 16))
+                                        for lr in range(16):
+                                            for lq in range(4):
+                                                B[lq, lr] = xt[toff + (r * TC + cg * 4 + lq) * 16 + lr]
+                                        for j in range(NCO):
+                                            acc[wave, s, j] += A[j] @ B
+                for wave in range(4):
+                    for s in range(NSLOT):
+                        tap = wave + 4 * s
+                        if tap >= TAPS:
+                            continue
+                        for lr in range(16):
+                            ci = c0 + lr
+                            if ci >= c4:
+                                continue
+                            for j in range(NCO):
+                                for row in range(16):
+                                    co = co0 + j * 16 + row
+                                    if co < Cout:
+                                        part[bx, co, tap * c4 + ci] = acc[wave, s, j, row, lr]
+    assert not np.isnan(part).any(), 'unwritten partials'
+    got = part.sum(0).reshape(Cout, TAPS, c4)
+    err = np.abs(got - ref).max() / np.abs(ref).max()
+    print(f'wgrad N{N} {H}x{W} Cin{Cin} Cout{Cout} k{KS} reflect{reflect} nz{nz}: rel err {err:.2e}')
+    assert err < 1e-12
+
+
+if __name__ == '__main__':
+    run_wgrad(1, 9, 35, 22, 18, 5, True, 2)
+    run_wgrad(2, 8, 40, 18, 40, 3, False, 3)
+    run_wgrad(1, 16, 32, 6, 7, 5, False, 1)
+    print('wgrad ok')
