@@ -3,6 +3,7 @@
 // filter lives in LDS as [tap][channel] so a tap is one ds_read_b128 per lane.
 // Reference: the groups=midp ConvBNReLU conv of InvertedResidualChannels (models/modules/inception_modules.py:166-173).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 using cat::cdiv;
@@ -98,7 +99,8 @@ __global__ __launch_bounds__(256) void dw_dgrad_kernel(DwArgs p, int Hin, int Wi
 
 // dw[c][tap] partials: lanes = (pixel-lane, channel quad); each lane keeps one float4 accumulator per tap of ONE filter row
 // (blockIdx.y = ky) to bound registers at kw*4; block-reduced through LDS; partial [nb][taps][cs] in ws.
-template <int KW>
+// IT = index type of the pixel walk (int64_t, or int with CAT_IDX32=1 when N*Ho*Wo < 2^31: the two div/mods per pixel are emulated at 64 bits)
+template <int KW, typename IT>
 __global__ __launch_bounds__(256) void dw_wgrad_kernel(DwArgs p, float* __restrict__ part, int nb, int ppl) {
   __shared__ f4 red[256];
   const int nq = p.xcs / 4;
@@ -111,15 +113,15 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(DwArgs p, float* __restri
 #pragma unroll
   for (int k = 0; k < KW; ++k) acc[k] = f4{0.f, 0.f, 0.f, 0.f};
   if (pl < ppl) {
-    for (int64_t q = pbeg + pl; q < pend; q += ppl) {
+    for (IT q = (IT)(pbeg + pl); q < (IT)pend; q += (IT)ppl) {
       const int ox = (int)(q % p.Wo);
-      const int64_t r = q / p.Wo;
+      const IT r = q / p.Wo;
       const int oy = (int)(r % p.Ho);
       const int n = (int)(r / p.Ho);
       int iy = oy - p.pad + ky;
       if (p.reflect) iy = cat::reflect_idx(iy, p.H);
       else if ((unsigned)iy >= (unsigned)p.H) continue;
-      const f4 gv = *reinterpret_cast<const f4*>(p.y + q * p.ycs + cq * 4);  // p.y = dy here (read only)
+      const f4 gv = *reinterpret_cast<const f4*>(p.y + (int64_t)q * p.ycs + cq * 4);  // p.y = dy here (read only)
       const float* xr = p.x + ((int64_t)n * p.H + iy) * p.W * p.xcs + cq * 4;
 #pragma unroll
       for (int kx = 0; kx < KW; ++kx) {
@@ -232,13 +234,20 @@ int cat_dwconv2d_wgrad(const cat_conv_t* g, const float* x, const float* dy, flo
   hipStream_t s = (hipStream_t)stream;
   cat::ProfScope prof("dwconv_wgrad", 2.0 * g->N * g->Ho * g->Wo * g->Cin * g->kh * g->kw, 2 * 4.0 * (double)g->N * g->Ho * g->Wo * g->ycs, stream);
   dim3 grid(pl.nb, g->kh);
+  static const int idx32_on = getenv("CAT_IDX32") ? atoi(getenv("CAT_IDX32")) : 0;
+  const bool i32 = idx32_on && (int64_t)g->N * g->Ho * g->Wo < (int64_t)2147483647 - 65536;
+#define DW_WGRAD(KW)                                                                             \
+  if (i32) dw_wgrad_kernel<KW, int><<<grid, 256, 0, s>>>(a, (float*)ws, pl.nb, pl.ppl);          \
+  else dw_wgrad_kernel<KW, int64_t><<<grid, 256, 0, s>>>(a, (float*)ws, pl.nb, pl.ppl);          \
+  break
   switch (g->kw) {
-    case 1: dw_wgrad_kernel<1><<<grid, 256, 0, s>>>(a, (float*)ws, pl.nb, pl.ppl); break;
-    case 3: dw_wgrad_kernel<3><<<grid, 256, 0, s>>>(a, (float*)ws, pl.nb, pl.ppl); break;
-    case 5: dw_wgrad_kernel<5><<<grid, 256, 0, s>>>(a, (float*)ws, pl.nb, pl.ppl); break;
-    case 7: dw_wgrad_kernel<7><<<grid, 256, 0, s>>>(a, (float*)ws, pl.nb, pl.ppl); break;
+    case 1: DW_WGRAD(1);
+    case 3: DW_WGRAD(3);
+    case 5: DW_WGRAD(5);
+    case 7: DW_WGRAD(7);
     default: CAT_REQUIRE(false, "dwconv wgrad: kw %d unsupported", g->kw);
   }
+#undef DW_WGRAD
   dw_wgrad_final_kernel<<<cdiv(g->Cin * g->kh * g->kw, 256), 256, 0, s>>>((const float*)ws, dw, g->Cin, g->xcs, g->kh * g->kw, pl.nb,
                                                                             accumulate);
   return cat::check_launch("dwconv2d_wgrad");

@@ -6,6 +6,7 @@
 // Reduction layout: a workgroup walks pixels with (256 / quads) pixel-lanes x quads channel-quads, so every global
 // access is a float4 and a wave touches whole pixels (cs*4 contiguous bytes); cross-lane combine goes through LDS.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 using cat::cdiv;
@@ -149,19 +150,22 @@ __global__ __launch_bounds__(256) void norm_fwd_finalize_kernel(const float* __r
 }
 
 // y = act(x * scale[g][c] + shift[g][c]); scale/shift hold zeros on padding channels.
+// IT = index type of the element walk: int64_t, or int (opt-in, CAT_IDX32=1) when the tensor has < 2^31 quads -- the `%` and `/` below are
+// emulated in ~100 instructions each at 64 bits, which is most of what these HBM-bound kernels execute per float4.
+template <typename IT>
 __global__ __launch_bounds__(256) void norm_apply_kernel(const float* __restrict__ x, const float* __restrict__ scale,
-                                                         const float* __restrict__ shift, float* __restrict__ y, int64_t nquads, int nq,
-                                                         int64_t qpg, int cs, int act, float slope) {
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nquads; i += (int64_t)gridDim.x * 256) {
+                                                         const float* __restrict__ shift, float* __restrict__ y, IT nquads, int nq,
+                                                         IT qpg, int cs, int act, float slope) {
+  for (IT i = (IT)blockIdx.x * 256 + threadIdx.x; i < nquads; i += (IT)gridDim.x * 256) {
     const int cq = (int)(i % nq);
     const int g = (int)(i / qpg);
-    const f4 v = *reinterpret_cast<const f4*>(x + i * 4);
+    const f4 v = *reinterpret_cast<const f4*>(x + (int64_t)i * 4);
     const f4 sc = *reinterpret_cast<const f4*>(scale + g * cs + cq * 4);
     const f4 sh = *reinterpret_cast<const f4*>(shift + g * cs + cq * 4);
     f4 o = v * sc + sh;
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = cat::apply_act(o[e], act, slope);
-    *reinterpret_cast<f4*>(y + i * 4) = o;
+    *reinterpret_cast<f4*>(y + (int64_t)i * 4) = o;
   }
 }
 
@@ -212,18 +216,19 @@ __global__ __launch_bounds__(256) void norm_bwd_param_kernel(const float* __rest
 }
 
 // dx = gamma*rstd * (g - mean(g) - xhat * mean(g*xhat))
+template <typename IT>
 __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
                                                              const float* __restrict__ c1, const float* __restrict__ c2,
-                                                             const float* __restrict__ scale, float* __restrict__ dx, int64_t nquads,
-                                                             int nq, int64_t qpg, int C, int cs, int act, float slope) {
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nquads; i += (int64_t)gridDim.x * 256) {
+                                                             const float* __restrict__ scale, float* __restrict__ dx, IT nquads,
+                                                             int nq, IT qpg, int C, int cs, int act, float slope) {
+  for (IT i = (IT)blockIdx.x * 256 + threadIdx.x; i < nquads; i += (IT)gridDim.x * 256) {
     const int cq = (int)(i % nq);
     const int g = (int)(i / qpg);
     const int c = cq * 4;
-    const f4 xv = *reinterpret_cast<const f4*>(x + i * 4);
-    f4 gv = *reinterpret_cast<const f4*>(dy + i * 4);
+    const f4 xv = *reinterpret_cast<const f4*>(x + (int64_t)i * 4);
+    f4 gv = *reinterpret_cast<const f4*>(dy + (int64_t)i * 4);
     const f4 m1 = *reinterpret_cast<const f4*>(c1 + g * cs + c);
     const f4 m2 = *reinterpret_cast<const f4*>(c2 + g * cs + c);
     const f4 sc = *reinterpret_cast<const f4*>(scale + g * cs + c);
@@ -240,7 +245,7 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* __rest
       }
       o[e] = sc[e] * (gg - m1[e] - xh * m2[e]);
     }
-    *reinterpret_cast<f4*>(dx + i * 4) = o;
+    *reinterpret_cast<f4*>(dx + (int64_t)i * 4) = o;
   }
 }
 
@@ -253,22 +258,29 @@ __global__ void bn_fold_kernel(const float* gamma, const float* beta, const floa
   shift[c] = (beta ? beta[c] : 0.f) - rm[c] * s;
 }
 
+template <typename IT>
 __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ x, const float* __restrict__ scale,
-                                                         const float* __restrict__ shift, float* __restrict__ y, int64_t nquads, int nq,
+                                                         const float* __restrict__ shift, float* __restrict__ y, IT nquads, int nq,
                                                          int C, int act, float slope) {
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nquads; i += (int64_t)gridDim.x * 256) {
+  for (IT i = (IT)blockIdx.x * 256 + threadIdx.x; i < nquads; i += (IT)gridDim.x * 256) {
     const int c = (int)(i % nq) * 4;
-    const f4 v = *reinterpret_cast<const f4*>(x + i * 4);
+    const f4 v = *reinterpret_cast<const f4*>(x + (int64_t)i * 4);
     f4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = c + e < C ? cat::apply_act(v[e] * scale[c + e] + shift[c + e], act, slope) : 0.f;
-    *reinterpret_cast<f4*>(y + i * 4) = o;
+    *reinterpret_cast<f4*>(y + (int64_t)i * 4) = o;
   }
 }
 
 int ew_grid(int64_t n) {
   int64_t b = (n + 255) / 256;
   return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+
+// 32-bit element walk (opt-in): the loop variable may run one grid stride (<= 8192 * 256) past nquads
+bool idx32(int64_t nquads) {
+  static const int on = getenv("CAT_IDX32") ? atoi(getenv("CAT_IDX32")) : 0;
+  return on && nquads < (int64_t)2147483647 - 8192 * 256;
 }
 
 }  // namespace
@@ -292,8 +304,12 @@ int cat_norm_fwd(const cat_norm_t* g, const float* x, const float* gamma, const 
                                                                    g->mode == CAT_NORM_BATCH ? running_var : nullptr, w + p.scale_off,
                                                                    w + p.shift_off, p.G, p.Pg, g->C, g->cs, p.nb, g->eps, g->momentum);
   const int64_t nquads = (int64_t)g->N * g->HW * p.nq;
-  norm_apply_kernel<<<ew_grid(nquads), 256, 0, s>>>(x, w + p.scale_off, w + p.shift_off, y, nquads, p.nq, (int64_t)p.Pg * p.nq, g->cs,
-                                                     g->act, g->slope);
+  if (idx32(nquads))
+    norm_apply_kernel<int><<<ew_grid(nquads), 256, 0, s>>>(x, w + p.scale_off, w + p.shift_off, y, (int)nquads, p.nq, p.Pg * p.nq, g->cs,
+                                                            g->act, g->slope);
+  else
+    norm_apply_kernel<int64_t><<<ew_grid(nquads), 256, 0, s>>>(x, w + p.scale_off, w + p.shift_off, y, nquads, p.nq, (int64_t)p.Pg * p.nq,
+                                                                g->cs, g->act, g->slope);
   return cat::check_launch("norm_fwd");
 }
 
@@ -314,9 +330,14 @@ int cat_norm_bwd(const cat_norm_t* g, const float* x, const float* dy, const flo
   if (!one_group && (dgamma || dbeta))
     norm_bwd_param_kernel<<<cdiv(g->C, 256), 256, 0, s>>>(w + p.c1_off, w + p.c2_off, dgamma, dbeta, p.G, p.Pg, g->C, g->cs, accumulate);
   const int64_t nquads = (int64_t)g->N * g->HW * p.nq;
-  norm_bwd_apply_kernel<<<ew_grid(nquads), 256, 0, s>>>(x, dy, gamma, beta, save_mean, save_rstd, w + p.c1_off, w + p.c2_off,
-                                                         w + p.scale_off, dx, nquads, p.nq, (int64_t)p.Pg * p.nq, g->C, g->cs, g->act,
-                                                         g->slope);
+  if (idx32(nquads))
+    norm_bwd_apply_kernel<int><<<ew_grid(nquads), 256, 0, s>>>(x, dy, gamma, beta, save_mean, save_rstd, w + p.c1_off, w + p.c2_off,
+                                                                w + p.scale_off, dx, (int)nquads, p.nq, p.Pg * p.nq, g->C, g->cs, g->act,
+                                                                g->slope);
+  else
+    norm_bwd_apply_kernel<int64_t><<<ew_grid(nquads), 256, 0, s>>>(x, dy, gamma, beta, save_mean, save_rstd, w + p.c1_off, w + p.c2_off,
+                                                                    w + p.scale_off, dx, nquads, p.nq, (int64_t)p.Pg * p.nq, g->C, g->cs,
+                                                                    g->act, g->slope);
   return cat::check_launch("norm_bwd");
 }
 
@@ -331,7 +352,8 @@ int cat_affine_act_fwd(const float* x, const float* scale, const float* shift, f
   CAT_REQUIRE(cs % 4 == 0 && cs >= C, "affine_act: bad channel stride");
   const int64_t nquads = M * (cs / 4);
   cat::ProfScope prof("affine_act", 0.0, 8.0 * M * cs, stream);
-  affine_act_kernel<<<ew_grid(nquads), 256, 0, (hipStream_t)stream>>>(x, scale, shift, y, nquads, cs / 4, C, act, slope);
+  if (idx32(nquads)) affine_act_kernel<int><<<ew_grid(nquads), 256, 0, (hipStream_t)stream>>>(x, scale, shift, y, (int)nquads, cs / 4, C, act, slope);
+  else affine_act_kernel<int64_t><<<ew_grid(nquads), 256, 0, (hipStream_t)stream>>>(x, scale, shift, y, nquads, cs / 4, C, act, slope);
   return cat::check_launch("affine_act");
 }
 

@@ -13,6 +13,10 @@ for v in 0 1; do
   CAT_CONV_TILE=$v timeout 120 python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null |
     python -c "import json,sys; d=json.loads(sys.stdin.readline()); print('CAT_CONV_TILE=$v', d['value'], 'img/s', d['ms_per_step'], 'ms; student fwd', d['student_forward']['ms'], 'ms', d['student_forward']['tflops'], 'TF')"
 done > $out/bench_ab.txt 2>&1
+# 3a. 32-bit element walks in the norm / affine / depthwise-wgrad kernels: kernel + model parity with the switch on, then the step
+CAT_IDX32=1 timeout 150 python -m pytest tests/test_kernels_gpu.py tests/test_model_gpu.py -q --tb=line 2>&1 | tail -5 > $out/idx32_tests.txt
+CAT_IDX32=1 timeout 120 python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null |
+  python -c "import json,sys; d=json.loads(sys.stdin.readline()); print('CAT_IDX32=1', d['value'], 'img/s', d['ms_per_step'], 'ms; student fwd', d['student_forward']['ms'], 'ms')" >> $out/bench_ab.txt 2>&1
 # 3b. N-tile choice by padded-N cost (frozen teacher's 176-wide GEMM)
 CAT_TILE_BY_PAD=1 timeout 120 python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null |
   python -c "import json,sys; d=json.loads(sys.stdin.readline()); print('CAT_TILE_BY_PAD=1', d['value'], 'img/s', d['ms_per_step'], 'ms')" >> $out/bench_ab.txt 2>&1
