@@ -162,6 +162,9 @@ def main():
     ap.add_argument('--teacher-side-stream', type=int, default=0, help='c2: run the frozen teacher forward on a side stream (1 GPU)')
     ap.add_argument('--graph', type=int, default=1, help='1 (default): replay the step as one captured hipGraph on 1 GPU; 0: eager launches')
     args = ap.parse_args()
+    # stdout carries exactly ONE line, the JSON record: everything the build prints (pruning search log, ...) goes to stderr
+    json_out = sys.stdout
+    sys.stdout = sys.stderr
     spade = args.workload == 'spade'
     if args.batch is None:
         args.batch = 4 if spade else 16
@@ -271,7 +274,7 @@ def main():
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = (cpu_baseline_spade if spade else cpu_baseline)(opt, model, args)
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=json_out, flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
 
