@@ -24,6 +24,7 @@ import torch
 from . import _lib as L
 from . import nn as cnn
 from . import ops
+from . import optim
 
 
 def _affine(bn):
@@ -61,7 +62,11 @@ def _tensors(block):
 
 
 def _plan(block):
-    key = tuple((t.data_ptr(), t._version) for t in _tensors(block))
+    tensors = _tensors(block)
+    # weights owned by a FusedAdam change under torch's feet (raw-pointer kernels): such blocks -- a BatchNorm student run in eval mode by
+    # evaluate_model between training steps -- re-fold after every optimizer step; the frozen teacher (no optimizer) folds once
+    trainable = any(getattr(t, '_cat_grad_view', None) is not None for t in tensors)
+    key = (tuple((t.data_ptr(), t._version) for t in tensors), optim.weights_epoch() if trainable else -1)
     cached = getattr(block, '_cat_frozen', None)
     if cached is not None and cached['key'] == key:
         return cached

@@ -14,6 +14,20 @@ import torch
 
 from . import _lib as L
 
+# The kernels update parameters (and BatchNorm running statistics) through raw pointers, so torch's `_version` counters never move.
+# Caches derived from trainable weights (cat_amd/frozen.py folds an eval-mode block's weights once) key on this epoch instead:
+# it advances with every optimizer step, eager or replayed.
+_WEIGHTS_EPOCH = 0
+
+
+def weights_epoch():
+    return _WEIGHTS_EPOCH
+
+
+def _bump_weights_epoch():
+    global _WEIGHTS_EPOCH
+    _WEIGHTS_EPOCH += 1
+
 
 class FusedAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
@@ -99,6 +113,7 @@ class FusedAdam(torch.optim.Optimizer):
     def step(self, closure=None):
         if closure is not None:
             raise NotImplementedError('closures are not used by the distillers')
+        _bump_weights_epoch()
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         for group, f in zip(self.param_groups, self._ensure_flat()):
             if f is None:
@@ -118,6 +133,7 @@ class FusedAdam(torch.optim.Optimizer):
 
     def note_graph_replay(self):
         """A captured step was replayed: the device-side step counter advanced, keep the host mirror in sync."""
+        _bump_weights_epoch()
         for f in self._ensure_flat():
             if f is not None:
                 f['step'] += 1

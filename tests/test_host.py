@@ -152,3 +152,25 @@ def test_no_undefined_names_in_gpu_only_code():
         for f in files:
             bad += [(os.path.relpath(f, root), line, name) for line, name in lint.check(f)]
     assert not bad, bad
+
+
+def test_frozen_plan_cache_follows_optimizer_steps():
+    """The kernels update weights through raw pointers (torch's _version never moves): a block whose parameters belong to a FusedAdam --
+    a BatchNorm student run in eval mode by evaluate_model between training steps -- must re-fold its weights after every optimizer
+    step, while the frozen teacher folds once (cat_amd/frozen.py::_plan; folding itself is plain tensor arithmetic, so it runs here)."""
+    from cat_amd import frozen, networks, optim
+    opt = H.make_opt(norm='batch', track=True)
+    net = networks.define_G(3, 3, 16, 'inception_9blocks', 'batch', 0, 'normal', 0.02, [], opt=opt)
+    net.eval()
+    blk = net.features[0]
+    p1 = frozen._plan(blk)
+    assert frozen._plan(blk) is p1
+    w = blk.res_ops[0][1][0].weight
+    w.data.mul_(2.0)                                     # what the Adam kernel does: no version bump
+    assert frozen._plan(blk) is p1                       # not optimizer-owned (the teacher): folded once
+    w._cat_grad_view = torch.zeros(1)                    # as FusedAdam registers its parameters
+    p2 = frozen._plan(blk)
+    assert p2 is not p1 and frozen._plan(blk) is p2
+    optim._bump_weights_epoch()                          # FusedAdam.step / note_graph_replay
+    p3 = frozen._plan(blk)
+    assert p3 is not p2 and not torch.equal(p3['w_a'], p1['w_a'])
