@@ -12,6 +12,7 @@ from torch import nn
 
 from . import _lib as L
 from . import ops
+from . import optim
 
 
 class Padded:
@@ -106,7 +107,9 @@ def _folded_eval_bn(conv, bn, out_dim):
     into the conv's weight / bias once (cached until any of the tensors involved changes) and the norm kernel disappears.
     One-time setup arithmetic, not part of the per-step kernel stream."""
     tensors = [conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var]
-    key = tuple((t.data_ptr(), t._version) if t is not None else None for t in tensors)
+    # optimizer-owned weights are updated through raw pointers (no version bump): such layers re-fold after every optimizer step
+    trainable = any(getattr(t, '_cat_grad_view', None) is not None for t in tensors if t is not None)
+    key = (tuple((t.data_ptr(), t._version) if t is not None else None for t in tensors), optim.weights_epoch() if trainable else -1)
     cache = getattr(conv, '_cat_fold', None)
     if cache is not None and cache[0] == key:
         return cache[1], cache[2]

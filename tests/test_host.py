@@ -174,3 +174,15 @@ def test_frozen_plan_cache_follows_optimizer_steps():
     optim._bump_weights_epoch()                          # FusedAdam.step / note_graph_replay
     p3 = frozen._plan(blk)
     assert p3 is not p2 and not torch.equal(p3['w_a'], p1['w_a'])
+    # same rule for the conv + eval-BatchNorm fold of the down / up-sampling layers (cat_amd/nn.py::_folded_eval_bn)
+    from cat_amd import nn as cnn
+    conv, bn = net.down_sampling[4], net.down_sampling[5]
+    with torch.no_grad():
+        w1, _ = cnn._folded_eval_bn(conv, bn, 0)
+        conv.weight.data.mul_(2.0)
+        assert cnn._folded_eval_bn(conv, bn, 0)[0] is w1
+        conv.weight._cat_grad_view = torch.zeros(1)
+        w2, _ = cnn._folded_eval_bn(conv, bn, 0)
+        optim._bump_weights_epoch()
+        w3, _ = cnn._folded_eval_bn(conv, bn, 0)
+    assert w2 is not w1 and w3 is not w2 and torch.allclose(w3, 2 * w1)
