@@ -15,41 +15,35 @@ class InceptionSPADEGenerator(BaseNetwork):
     def modify_commandline_options(parser, is_train):
         return parser
 
+    # (attribute, width multiplier in, width multiplier out) of the SPADE blocks, in registration (= checkpoint key) order
+    _BLOCKS = (('head_0', 16, 16), ('G_middle_0', 16, 16), ('G_middle_1', 16, 16), ('up_0', 16, 8), ('up_1', 8, 4), ('up_2', 4, 2),
+               ('up_3', 2, 1))
+    _UP_LAYERS = {'normal': 5, 'more': 6, 'most': 7}      # x2 upsamplings between the latent map and the output
+
     def __init__(self, opt):
-        super(InceptionSPADEGenerator, self).__init__()
+        super().__init__()
         self.opt = opt
-        nf = opt.ngf
-        self.fc_norm = cnn.SynchronizedBatchNorm2d(16 * nf, affine=True)
+        base = opt.ngf
+        self.fc_norm = cnn.SynchronizedBatchNorm2d(16 * base, affine=True)
         self.sw, self.sh = self.compute_latent_vector_size(opt)
-        self.fc = cnn.Conv2d(self.opt.semantic_nc, 16 * nf, 3, padding=1)
-        self.head_0 = SPADEInvertedResidualChannels(16 * nf, 16 * nf, opt)
-        self.G_middle_0 = SPADEInvertedResidualChannels(16 * nf, 16 * nf, opt)
-        self.G_middle_1 = SPADEInvertedResidualChannels(16 * nf, 16 * nf, opt)
-        self.up_0 = SPADEInvertedResidualChannels(16 * nf, 8 * nf, opt)
-        self.up_1 = SPADEInvertedResidualChannels(8 * nf, 4 * nf, opt)
-        self.up_2 = SPADEInvertedResidualChannels(4 * nf, 2 * nf, opt)
-        self.up_3 = SPADEInvertedResidualChannels(2 * nf, 1 * nf, opt)
-        final_nc = nf
+        self.fc = cnn.Conv2d(opt.semantic_nc, 16 * base, 3, padding=1)
+        for attr, m_in, m_out in self._BLOCKS:
+            setattr(self, attr, SPADEInvertedResidualChannels(m_in * base, m_out * base, opt))
+        out_width = base
         if opt.num_upsampling_layers == 'most':
-            self.up_4 = SPADEInvertedResidualChannels(1 * nf, nf // 2, opt)
-            final_nc = nf // 2
-        self.conv_img = cnn.Conv2d(final_nc, 3, 3, padding=1)
+            out_width = base // 2
+            self.up_4 = SPADEInvertedResidualChannels(base, out_width, opt)
+        self.conv_img = cnn.Conv2d(out_width, 3, 3, padding=1)
         self.up = cnn.Upsample(scale_factor=2)
         self._lrelu = cnn.LeakyReLU(2e-1)
         self._tanh = cnn.Tanh()
 
     def compute_latent_vector_size(self, opt):
-        if opt.num_upsampling_layers == 'normal':
-            num_up_layers = 5
-        elif opt.num_upsampling_layers == 'more':
-            num_up_layers = 6
-        elif opt.num_upsampling_layers == 'most':
-            num_up_layers = 7
-        else:
+        """(width, height) of the map the generator starts from: crop_size / 2^(number of upsamplings), height by the aspect ratio."""
+        if opt.num_upsampling_layers not in self._UP_LAYERS:
             raise ValueError('opt.num_upsampling_layers [%s] not recognized' % opt.num_upsampling_layers)
-        sw = opt.crop_size // (2 ** num_up_layers)
-        sh = round(sw / opt.aspect_ratio)
-        return sw, sh
+        width = opt.crop_size // (1 << self._UP_LAYERS[opt.num_upsampling_layers])
+        return width, round(width / opt.aspect_ratio)
 
     def forward(self, input, mapping_layers=[]):
         seg = ops.conform(input)
@@ -80,9 +74,7 @@ class InceptionSPADEGenerator(BaseNetwork):
             x = self.up(x)
             x = keep('up_4', self.up_4(x, seg))
         x = self.conv_img(self._lrelu(x), fuse_act=self._tanh)      # F.leaky_relu(x, 2e-1) -> conv_img -> tanh (:117-118)
-        if len(mapping_layers) == 0:
-            return x
-        return x, ret_acts
+        return (x, ret_acts) if len(mapping_layers) else x
 
     def remove_spectral_norm(self):
         raise NotImplementedError('remove_spectral_norm belongs to the export path (out of scope)')
