@@ -2,7 +2,6 @@
 (SPADENLayer / Multiscale, `discriminator_{i}.model{j}` keys)."""
 import functools
 
-import numpy as np
 import torch
 from torch import nn
 
@@ -13,27 +12,21 @@ from .inception_modules import get_active_fn
 
 
 class NLayerDiscriminator(BaseNetwork):
+    """70x70-style PatchGAN: 4x4 convs, stride 2 for the first `n_layers` (widths ndf * min(2^i, 8)), then two stride-1 convs down to one
+    channel; every conv but the first and the last is followed by norm + LeakyReLU(0.2) and carries a bias only with InstanceNorm."""
+
     def __init__(self, input_nc, ndf=64, n_layers=3, norm_layer=cnn.BatchNorm2d, active_fn='nn.LeakyReLU'):
-        super(NLayerDiscriminator, self).__init__()
-        if type(norm_layer) == functools.partial:
-            use_bias = issubclass(norm_layer.func, nn.InstanceNorm2d)
-        else:
-            use_bias = issubclass(norm_layer, nn.InstanceNorm2d)
-        active_fn = get_active_fn(active_fn)
-        kw, padw = 4, 1
-        sequence = [cnn.Conv2d(input_nc, ndf, kernel_size=kw, stride=2, padding=padw), active_fn(0.2)]
-        nf_mult = 1
-        for n in range(1, n_layers):
-            nf_mult_prev = nf_mult
-            nf_mult = min(2 ** n, 8)
-            sequence += [cnn.Conv2d(ndf * nf_mult_prev, ndf * nf_mult, kernel_size=kw, stride=2, padding=padw, bias=use_bias),
-                         norm_layer(ndf * nf_mult), active_fn(0.2)]
-        nf_mult_prev = nf_mult
-        nf_mult = min(2 ** n_layers, 8)
-        sequence += [cnn.Conv2d(ndf * nf_mult_prev, ndf * nf_mult, kernel_size=kw, stride=1, padding=padw, bias=use_bias),
-                     norm_layer(ndf * nf_mult), active_fn(0.2)]
-        sequence += [cnn.Conv2d(ndf * nf_mult, 1, kernel_size=kw, stride=1, padding=padw)]
-        self.model = cnn.FusedSequential(*sequence)
+        super().__init__()
+        norm_cls = norm_layer.func if isinstance(norm_layer, functools.partial) else norm_layer
+        bias = issubclass(norm_cls, nn.InstanceNorm2d)
+        act = get_active_fn(active_fn)
+        widths = [ndf * min(2 ** i, 8) for i in range(n_layers + 1)]
+        layers = [cnn.Conv2d(input_nc, widths[0], kernel_size=4, stride=2, padding=1), act(0.2)]
+        for i in range(1, n_layers + 1):
+            stride = 2 if i < n_layers else 1
+            layers += [cnn.Conv2d(widths[i - 1], widths[i], kernel_size=4, stride=stride, padding=1, bias=bias), norm_layer(widths[i]), act(0.2)]
+        layers.append(cnn.Conv2d(widths[-1], 1, kernel_size=4, stride=1, padding=1))
+        self.model = cnn.FusedSequential(*layers)
 
     def forward(self, input):
         return self.model(input)
@@ -50,20 +43,18 @@ class SPADENLayerDiscriminator(BaseNetwork):
         super().__init__()
         from .normalization import get_nonspade_norm_layer
         self.opt = opt
-        kw = 4
-        padw = int(np.ceil((kw - 1.0) / 2))
-        nf = opt.ndf
-        input_nc = self.compute_D_input_nc(opt)
-        norm_layer = get_nonspade_norm_layer(opt, opt.norm_D)
-        sequence = [[cnn.Conv2d(input_nc, nf, kernel_size=kw, stride=2, padding=padw), cnn.LeakyReLU(0.2, False)]]
-        for n in range(1, opt.n_layers_D):
-            nf_prev = nf
-            nf = min(nf * 2, 512)
-            stride = 1 if n == opt.n_layers_D - 1 else 2
-            sequence += [[norm_layer(cnn.Conv2d(nf_prev, nf, kernel_size=kw, stride=stride, padding=padw)), cnn.LeakyReLU(0.2, False)]]
-        sequence += [[cnn.Conv2d(nf, 1, kernel_size=kw, stride=1, padding=padw)]]
-        for n in range(len(sequence)):
-            self.add_module('model' + str(n), cnn.FusedSequential(*sequence[n]))
+        wrap = get_nonspade_norm_layer(opt, opt.norm_D)
+        pad = 2                                              # ceil((4 - 1) / 2)
+        widths = [opt.ndf]
+        for _ in range(1, opt.n_layers_D):
+            widths.append(min(2 * widths[-1], 512))
+        stages = [[cnn.Conv2d(self.compute_D_input_nc(opt), widths[0], kernel_size=4, stride=2, padding=pad), cnn.LeakyReLU(0.2, False)]]
+        for i in range(1, opt.n_layers_D):
+            stride = 2 if i < opt.n_layers_D - 1 else 1
+            stages.append([wrap(cnn.Conv2d(widths[i - 1], widths[i], kernel_size=4, stride=stride, padding=pad)), cnn.LeakyReLU(0.2, False)])
+        stages.append([cnn.Conv2d(widths[-1], 1, kernel_size=4, stride=1, padding=pad)])
+        for i, stage in enumerate(stages):
+            self.add_module('model%d' % i, cnn.FusedSequential(*stage))
 
     def compute_D_input_nc(self, opt):
         return opt.semantic_nc + opt.output_nc
