@@ -33,31 +33,38 @@ def get_scheduler(optimizer, opt):
     raise NotImplementedError('learning rate policy [%s] is not implemented' % opt.lr_policy)
 
 
+_WEIGHT_INIT = {
+    'normal': lambda w, gain: init.normal_(w, 0.0, gain),
+    'xavier': lambda w, gain: init.xavier_normal_(w, gain=gain),
+    'kaiming': lambda w, gain: init.kaiming_normal_(w, a=0, mode='fan_in'),
+    'orthogonal': lambda w, gain: init.orthogonal_(w, gain=gain),
+}
+
+
 def init_weights(net, init_type='normal', init_gain=0.02, verbose=False):
-    def init_func(m):
-        classname = m.__class__.__name__
-        if hasattr(m, 'weight') and (classname.find('Conv') != -1 or classname.find('Linear') != -1):
-            if init_type == 'normal':
-                init.normal_(m.weight.data, 0.0, init_gain)
-            elif init_type == 'xavier':
-                init.xavier_normal_(m.weight.data, gain=init_gain)
-            elif init_type == 'kaiming':
-                init.kaiming_normal_(m.weight.data, a=0, mode='fan_in')
-            elif init_type == 'orthogonal':
-                init.orthogonal_(m.weight.data, gain=init_gain)
-            else:
+    """reference networks.py:106-147: conv / linear weights by `init_type`, their biases 0; BatchNorm2d weights N(1, gain), biases 0.
+    Modules are matched by class NAME (so SynchronizedBatchNorm2d counts as BatchNorm2d, InstanceNorm2d keeps its defaults), in
+    `net.apply` order -- the order in which the random stream is consumed."""
+    fill = _WEIGHT_INIT.get(init_type)
+
+    def visit(m):
+        kind = type(m).__name__
+        if not hasattr(m, 'weight'):                         # containers (ConvBNReLU ...) are matched by name too, but own no weight
+            return
+        if 'Conv' in kind or 'Linear' in kind:
+            if fill is None:
                 raise NotImplementedError('initialization method [%s] is not implemented' % init_type)
-            if hasattr(m, 'bias') and m.bias is not None:
+            fill(m.weight.data, init_gain)
+            if getattr(m, 'bias', None) is not None:
                 init.constant_(m.bias.data, 0.0)
-        elif classname.find('BatchNorm2d') != -1:
-            if hasattr(m, 'weight') and m.weight is not None:
-                init.normal_(m.weight.data, 1.0, init_gain)
-            if hasattr(m, 'bias') and m.weight is not None:
+        elif 'BatchNorm2d' in kind and m.weight is not None:
+            init.normal_(m.weight.data, 1.0, init_gain)
+            if getattr(m, 'bias', None) is not None:
                 init.constant_(m.bias.data, 0.0)
 
     if verbose:
         print('initialize network with %s' % init_type)
-    net.apply(init_func)
+    net.apply(visit)
 
 
 def init_net(net, init_type='normal', init_gain=0.02, gpu_ids=[]):
