@@ -24,12 +24,25 @@ class NormGeom(C.Structure):
                 ('act', c_i), ('slope', c_f)]
 
 
+TCONV_MAXSEG = 8
+
+
+class TSeg(C.Structure):
+    _fields_ = [('src', c_p), ('scale', c_p), ('shift', c_p), ('xcs', c_i), ('c4', c_i), ('ks', c_i), ('padv', c_i), ('act', c_i),
+                ('slope', c_f), ('reflect', c_i), ('pack_off', c_i)]
+
+
+class TConv(C.Structure):
+    _fields_ = [(n, c_i) for n in ('N', 'H', 'W', 'Ho', 'Wo', 'Nn', 'ycs', 'ycw', 'act')] + [('slope', c_f), ('nseg', c_i),
+                                                                                            ('seg', TSeg * TCONV_MAXSEG)]
+
+
 PAD_ZERO, PAD_REFLECT = 0, 1
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
 NORM_INSTANCE, NORM_BATCH = 0, 1
 LOSS_L1, LOSS_LSGAN, LOSS_HINGE_D_REAL, LOSS_HINGE_D_FAKE, LOSS_NEG_MEAN, LOSS_MSE = range(6)
 
-_G, _NG = C.POINTER(ConvGeom), C.POINTER(NormGeom)
+_G, _NG, _TG = C.POINTER(ConvGeom), C.POINTER(NormGeom), C.POINTER(TConv)
 # name -> (restype, argtypes); mirrors include/cat_hip.h one to one (tests check every symbol is exported)
 SIGNATURES = {
     'cat_hip_last_error': (C.c_char_p, []),
@@ -42,6 +55,9 @@ SIGNATURES = {
     'cat_conv2d_dgrad_ws_bytes': (C.c_size_t, [_G, c_i]),
     'cat_conv2d_dgrad_ws': (c_i, [_G, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p]),
     'cat_conv2d_wgrad': (c_i, [_G, c_p, c_p, c_p, c_i, c_p, c_p]),
+    'cat_tconv_pack_floats': (C.c_size_t, [c_i, c_i, c_i]),
+    'cat_tconv_pack': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
+    'cat_tconv_fwd': (c_i, [_TG, c_p, c_p, c_p, c_p]),
     'cat_dwconv2d_fwd': (c_i, [_G, c_p, c_p, c_p, c_p, c_p]),
     'cat_dwconv2d_dgrad': (c_i, [_G, c_p, c_p, c_p, c_i, c_p]),
     'cat_dwconv2d_wgrad': (c_i, [_G, c_p, c_p, c_p, c_i, c_p, c_p]),

@@ -1,0 +1,405 @@
+// LDS-tile convolution with pre-packed filter fragments ("tconv"), stride 1, k in {1, 3, 5}, NHWC fp32, gfx950.
+//
+//   out[n][oy][ox][co] = act( bias[co] + sum over K SEGMENTS s, taps (ky, kx) of s, channels c of s
+//                                         f_s(src_s[n][oy - padv_s + ky][ox - padv_s + kx][c]) * W_s(tap, c, co) )
+//
+// One kernel body serves
+//   * a single "same" convolution (one segment): the pruned student's ragged 77 -> 7..23 and 7..23 -> 77 layers and the
+//     teacher's 256 -> 42 -> 256 pairs (models/modules/inception_modules.py:135-147), whose im2col kernels re-fetch the A operand
+//     from L2 once per tap (13x over-fetch measured on 256 -> 42 5x5);
+//   * its input gradient (segment source = dy, filters packed transposed + flipped, padv = k - 1 - pad);
+//   * the K-CONCATENATED sum of several convolutions of different kernel sizes reading different tensors -- the branch sum of
+//     InvertedResidualChannels.forward (:230-236: sum_k res_k(x) + sum_k dw_k(x) as ONE launch writing the sum once), and the sum
+//     of the six first-conv input gradients in the backward pass;
+//   * f_s = optional per-channel affine + activation applied while the tile is staged (a train-mode norm's apply pass folded
+//     into the consumer: no normalised copy of the hidden tensor is written to HBM).
+//
+// Workgroup = 256 threads = 4 wave64 = 8 x TW output pixels (TW = 16 or 32); wave w owns rows 2w, 2w+1 as MT = TW/8 M-tiles of
+// 16 consecutive pixels.  Per 16-channel chunk the (8 + halo) x (TW + halo) source patch is staged ONCE in LDS as
+// [row][col][16 ch + 4 pad] (double buffered, one barrier per chunk); the K index inside a chunk runs over (tap, channel quad)
+// PAIRS, four pairs per v_mfma_f32_16x16x4_f32 group (lane quarter lq <-> pair 4g + lq), so ragged channel counts cost at most
+// one partially filled group per chunk instead of a zero-padded 16-channel chunk per tap (18 hidden channels: K efficiency 0.56
+// -> 0.98).  The A fragment of (M-tile, group) is one ds_read_b128 at a per-lane offset read from a small LDS table; the B
+// fragments come from a stream that cat_tconv_pack laid out in exactly the order the kernel consumes it ([chunk][group][N-tile]
+// [lane][4]: one coalesced 1 KB global_load_dwordx4 per wave, no address arithmetic on the vector ALU, which on gfx950 shares
+// its issue slots with the fp32 MFMA).  Filters of trainable layers are re-packed once per optimizer step.
+#include "common.h"
+#include <stdlib.h>
+
+namespace cat_pk {
+
+constexpr int TH = 8, PITCH = 20, TABN = 128;
+
+__device__ __attribute__((aligned(16))) float g_zero[4] = {0.f, 0.f, 0.f, 0.f};
+
+struct Launch {
+  int hl, tr, tc;          // halo (left / top), staged rows / columns
+  int tiles_x, tiles;      // output tiles per row / per image
+  int nt_total, nblk;      // 16-wide N tiles of the output, N blocks (gridDim.x = N * tiles * nblk)
+};
+
+template <int NT, int TW>
+__global__ __launch_bounds__(256) void tconv_kernel(const cat_tconv_t g, const float* __restrict__ pack, const float* __restrict__ bias,
+                                                    float* __restrict__ y, const Launch L) {
+  constexpr int MT = TW / 8;
+  constexpr int MAXIT = ((TH + 4) * (TW + 4) * 4 + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tile_floats = L.tr * L.tc * PITCH;
+  float* tile0 = smem;
+  int* tab0 = reinterpret_cast<int*>(smem + 2 * tile_floats);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lq = lane >> 4;
+  // block -> (image, tile, N block): N blocks of one tile are adjacent (they stage the same patch), tiles of one image adjacent
+  const int bid = cat::xcd_remap(blockIdx.x, gridDim.x);
+  const int nb = bid % L.nblk, tt = bid / L.nblk;
+  const int n = tt / L.tiles, t = tt - n * L.tiles;
+  const int oy0 = (t / L.tiles_x) * TH, ox0 = (t % L.tiles_x) * TW;
+  const int j0 = nb * NT;
+  const int slots = L.tr * L.tc * 4;
+  const int quad = tid & 3;
+
+  // staging map: this thread's patch pixels (independent of the segment)
+  int sy[MAXIT], sx[MAXIT];
+#pragma unroll
+  for (int it = 0; it < MAXIT; ++it) {
+    const int pix = (tid + it * 256) >> 2;
+    const int r = pix / L.tc;
+    sy[it] = oy0 - L.hl + r;
+    sx[it] = ox0 - L.hl + (pix - r * L.tc);
+  }
+
+  // cursor over (segment, 16-channel chunk)
+  int cs_ = 0, cc0 = 0;                 // segment, first channel of the chunk
+  int64_t cpack = g.seg[0].pack_off;    // float offset of the chunk's packed filters
+  unsigned soff[MAXIT];
+  unsigned smask = 0;
+  auto locate = [&](int s) {   // source offsets of the patch pixels for segment s
+    const int refl = g.seg[s].reflect, xcs = g.seg[s].xcs;
+    smask = 0;
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+      int iy = sy[it], ix = sx[it];
+      bool v = tid + it * 256 < slots;
+      if (refl) {
+        v = v && iy > -g.H && iy < 2 * g.H - 1 && ix > -g.W && ix < 2 * g.W - 1;
+        iy = cat::reflect_idx(iy, g.H);
+        ix = cat::reflect_idx(ix, g.W);
+      } else {
+        v = v && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
+      }
+      smask |= v ? (1u << it) : 0u;
+      soff[it] = v ? ((unsigned)(n * g.H + iy) * (unsigned)g.W + (unsigned)ix) * (unsigned)xcs + quad * 4 : 0u;   // < 2^32 elements (host-checked)
+    }
+  };
+  f4 sreg[MAXIT], ssc, ssh;
+  int s_act = 0;
+  float s_neg = 1.f;
+  bool s_aff = false, s_qv = false;
+  auto gload = [&](int s, int c0) {
+    const float* src = g.seg[s].src;
+    s_qv = c0 + quad * 4 < g.seg[s].c4;
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+      const bool v = ((smask >> it) & 1u) && s_qv;
+      sreg[it] = *reinterpret_cast<const f4*>(v ? src + soff[it] + c0 : g_zero);
+    }
+    s_aff = g.seg[s].scale != nullptr;
+    s_act = g.seg[s].act;
+    s_neg = s_act == CAT_ACT_RELU ? 0.f : (s_act == CAT_ACT_LRELU ? g.seg[s].slope : 1.f);
+    if (s_aff) {
+      ssc = *reinterpret_cast<const f4*>(s_qv ? g.seg[s].scale + c0 + quad * 4 : g_zero);
+      ssh = *reinterpret_cast<const f4*>(s_qv ? g.seg[s].shift + c0 + quad * 4 : g_zero);
+    }
+  };
+  auto sstore = [&](int buf, int s, int c0) {
+    float* tile = tile0 + buf * tile_floats;
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+      const int idx = tid + it * 256;
+      f4 v = sreg[it];
+      if (s_aff || s_act) {   // wave-uniform
+        const bool ok = ((smask >> it) & 1u) && s_qv;   // padding pixels / channels stay exactly 0
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float a = s_aff ? fmaf(v[e], ssc[e], ssh[e]) : v[e];
+          a = a > 0.f ? a : a * s_neg;      // s_neg: 0 (ReLU), slope (LeakyReLU), 1 (none)
+          v[e] = ok ? a : 0.f;
+        }
+      }
+      if (idx < slots) *reinterpret_cast<f4*>(tile + (idx >> 2) * PITCH + quad * 4) = v;
+    }
+    // per-lane-quarter A offsets of every MFMA group of this chunk: pair p = 4 g + lq -> (tap, channel quad)
+    const int ks = g.seg[s].ks, taps = ks * ks;
+    const int nq = min(4, (g.seg[s].c4 - c0) >> 2);
+    const int ngr = (taps * nq + 3) >> 2;
+    if (tid < TABN) {
+      int off = 0;
+      if (tid < ngr * 4) {
+        const int tap = tid / nq, qd = tid - tap * nq;
+        if (tap < taps) {
+          const int ky = tap / ks, kx = tap - ky * ks;
+          const int d = L.hl - g.seg[s].padv;
+          off = ((d + ky) * L.tc + d + kx) * PITCH + qd * 4;
+        }
+      }
+      tab0[buf * TABN + tid] = off;
+    }
+  };
+
+  f4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+
+  int abase[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int row = 2 * wave + (MT == 2 ? i : (i >> 1)), col = (MT == 2 ? 0 : (i & 1) * 16) + lr;
+    abase[i] = (row * L.tc + col) * PITCH;
+  }
+  // B stream of this lane: [group][N tile][lane][4]; tiles beyond the output's last one re-read the last valid tile (masked at the store)
+  // packed filters through a buffer resource: per-lane byte offset in voffset, the group's offset in soffset (scalar) -- no vector
+  // ALU address arithmetic in the MFMA stream
+  const __amdgpu_buffer_rsrc_t prsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pack), 0, 0x7fffffff, 0x00020000);
+  auto bload = [&](unsigned voff, unsigned soff_) {
+    const auto r = __builtin_amdgcn_raw_buffer_load_b128(prsrc, voff, soff_, 0);
+    static_assert(sizeof(r) == sizeof(f4), "buffer load width");
+    return __builtin_bit_cast(f4, r);
+  };
+  unsigned jb[NT];   // byte offsets inside one group
+#pragma unroll
+  for (int j = 0; j < NT; ++j) jb[j] = (unsigned)(min(j0 + j, L.nt_total - 1) * 64 + lane) * 16u;
+  const int gstride = L.nt_total * 256;
+
+  locate(0);
+  gload(0, 0);
+  sstore(0, 0, 0);
+  __syncthreads();
+  int buf = 0;
+  while (true) {
+    // next chunk
+    int ns = cs_, nc0 = cc0 + 16;
+    const int ks = g.seg[cs_].ks, taps = ks * ks;
+    const int nq = min(4, (g.seg[cs_].c4 - cc0) >> 2);
+    const int ngr = (taps * nq + 3) >> 2;
+    int64_t npack = cpack + (int64_t)ngr * gstride;
+    if (nc0 >= g.seg[cs_].c4) {
+      ++ns;
+      nc0 = 0;
+      if (ns < g.nseg) {
+        npack = g.seg[ns].pack_off;
+        locate(ns);
+      }
+    }
+    const bool more = ns < g.nseg;
+    if (more) gload(ns, nc0);   // in flight behind this chunk's MFMA stream
+
+    {
+      // MFMA stream of this chunk.  Two operand register sets in ping-pong (no copies), the operands of group g+1 and the A offset
+      // of group g+2 are requested BEFORE the 4*MT*NT MFMAs of group g are issued, so no load is waited for in the same group.
+      const float* tile = tile0 + buf * tile_floats;
+      const int* tab = tab0 + buf * TABN + lq;
+      const unsigned gbytes = (unsigned)gstride * 4u;
+      const unsigned so = (unsigned)cpack * 4u;
+      const int last = ngr - 1;
+      f4 a0[MT], a1[MT], b0[NT], b1[NT];
+      int off = tab[0];
+      int offn = tab[4 * min(1, last)];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) a0[i] = *reinterpret_cast<const f4*>(tile + abase[i] + off);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) b0[j] = bload(jb[j], so);
+      int gi = 0;
+      while (true) {
+        {
+          const int g1 = min(gi + 1, last), g2 = min(gi + 2, last);
+#pragma unroll
+          for (int i = 0; i < MT; ++i) a1[i] = *reinterpret_cast<const f4*>(tile + abase[i] + offn);
+#pragma unroll
+          for (int j = 0; j < NT; ++j) b1[j] = bload(jb[j], so + (unsigned)g1 * gbytes);
+          offn = tab[4 * g2];
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int tq = 0; tq < 4; ++tq)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+              for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i][tq], b0[j][tq], acc[i][j], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (++gi >= ngr) break;
+        {
+          const int g1 = min(gi + 1, last), g2 = min(gi + 2, last);
+#pragma unroll
+          for (int i = 0; i < MT; ++i) a0[i] = *reinterpret_cast<const f4*>(tile + abase[i] + offn);
+#pragma unroll
+          for (int j = 0; j < NT; ++j) b0[j] = bload(jb[j], so + (unsigned)g1 * gbytes);
+          offn = tab[4 * g2];
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int tq = 0; tq < 4; ++tq)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+              for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[i][tq], b1[j][tq], acc[i][j], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (++gi >= ngr) break;
+      }
+    }
+    if (!more) break;
+    sstore(buf ^ 1, ns, nc0);
+    __syncthreads();
+    buf ^= 1;
+    cs_ = ns;
+    cc0 = nc0;
+    cpack = npack;
+  }
+
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int oy = oy0 + 2 * wave + (MT == 2 ? i : (i >> 1));
+    if (oy >= g.Ho) continue;
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      const int ox = ox0 + (MT == 2 ? 0 : (i & 1) * 16) + lq * 4 + rg;
+      if (ox >= g.Wo) continue;
+      float* yo = y + (((int64_t)n * g.Ho + oy) * g.Wo + ox) * g.ycs;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int co = (j0 + j) * 16 + lr;
+        if (j0 + j >= L.nt_total) continue;
+        if (co < g.Nn) yo[co] = cat::apply_act(acc[i][j][rg] + (bias ? bias[co] : 0.f), g.act, g.slope);
+        else if (co < g.ycw) yo[co] = 0.f;
+      }
+    }
+  }
+}
+
+// dst[(G * nt_total + j) * 256 + lane * 4 + e]: G enumerates the MFMA groups of all chunks of one segment in consumption order
+__global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ w, float* __restrict__ dst, int mode, int Nn, int Ck, int ks,
+                                                   int wcs, int wn, int c4, int nt_total, int64_t total4) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total4) return;
+  const int lane = (int)(e & 63);
+  const int64_t gj = e >> 6;
+  const int j = (int)(gj % nt_total);
+  int G = (int)(gj / nt_total);
+  const int taps = ks * ks;
+  const int nfull = c4 >> 4;
+  int chunk, gi, nq;
+  if (G < nfull * taps) {
+    chunk = G / taps;
+    gi = G - chunk * taps;
+    nq = 4;
+  } else {
+    chunk = nfull;
+    gi = G - nfull * taps;
+    nq = (c4 & 15) >> 2;
+  }
+  const int lr = lane & 15, lq = lane >> 4;
+  const int p = 4 * gi + lq;
+  const int tap = p / nq, qd = p - tap * nq;
+  const int nn = j * 16 + lr;
+  f4 v = {0.f, 0.f, 0.f, 0.f};
+  if (tap < taps && nn < Nn) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int c = chunk * 16 + qd * 4 + t;
+      if (c < Ck) v[t] = mode == 0 ? w[(int64_t)nn * wn + tap * wcs + c] : w[(int64_t)c * wn + (taps - 1 - tap) * wcs + nn];
+    }
+  }
+  *reinterpret_cast<f4*>(dst + e * 4) = v;
+}
+
+static int groups_of(int ks, int c4) {
+  const int taps = ks * ks;
+  const int nfull = c4 >> 4, rem = (c4 & 15) >> 2;
+  return nfull * taps + (rem ? (taps * rem + 3) / 4 : 0);
+}
+
+}  // namespace cat_pk
+
+extern "C" {
+
+size_t cat_tconv_pack_floats(int ks, int c4, int Nn) {
+  if (ks <= 0 || c4 <= 0 || (c4 & 3) || Nn <= 0) return 0;
+  return (size_t)cat_pk::groups_of(ks, c4) * cat::cdiv(Nn, 16) * 256;
+}
+
+int cat_tconv_pack(const float* w, int mode, int Nn, int Ck, int ks, int wcs, int wn, int c4, float* dst, cat_stream_t stream) {
+  CAT_REQUIRE(ks == 1 || ks == 3 || ks == 5, "tconv pack: kernel size %d unsupported", ks);
+  CAT_REQUIRE(c4 > 0 && (c4 & 3) == 0 && Ck <= c4 && Nn > 0, "tconv pack: bad channel counts (c4=%d Ck=%d Nn=%d)", c4, Ck, Nn);
+  CAT_REQUIRE(mode == 0 ? Ck <= wcs : Nn <= wcs, "tconv pack: filter rows shorter than the channels read");
+  const int nt = cat::cdiv(Nn, 16);
+  const int64_t total4 = (int64_t)cat_pk::groups_of(ks, c4) * nt * 64;
+  cat_pk::pack_kernel<<<(int)((total4 + 255) / 256), 256, 0, (hipStream_t)stream>>>(w, dst, mode, Nn, Ck, ks, wcs, wn, c4, nt, total4);
+  return cat::check_launch("tconv_pack");
+}
+
+int cat_tconv_fwd(const cat_tconv_t* g, const float* pack, const float* bias, float* y, cat_stream_t stream) {
+  CAT_REQUIRE(g->nseg >= 1 && g->nseg <= CAT_TCONV_MAXSEG, "tconv: %d segments", g->nseg);
+  CAT_REQUIRE(g->N > 0 && g->H > 0 && g->W > 0 && g->Ho > 0 && g->Wo > 0 && g->Nn > 0, "tconv: empty geometry");
+  CAT_REQUIRE((g->ycs & 3) == 0 && g->ycs >= g->Nn && g->ycw <= g->ycs, "tconv: bad output stride");
+  int hl = 0, hr = 0;
+  double kflops = 0.0;
+  for (int s = 0; s < g->nseg; ++s) {
+    const cat_tseg_t& sg = g->seg[s];
+    CAT_REQUIRE(sg.ks == 1 || sg.ks == 3 || sg.ks == 5, "tconv: kernel size %d unsupported", sg.ks);
+    CAT_REQUIRE(sg.c4 > 0 && (sg.c4 & 3) == 0 && (sg.xcs & 3) == 0 && sg.xcs >= sg.c4, "tconv: segment %d channel layout", s);
+    CAT_REQUIRE(sg.padv >= 0 && sg.padv < sg.ks, "tconv: segment %d padv", s);
+    CAT_REQUIRE(sg.act == CAT_ACT_NONE || sg.act == CAT_ACT_RELU || sg.act == CAT_ACT_LRELU, "tconv: staging activation %d", sg.act);
+    CAT_REQUIRE(!sg.reflect || (sg.ks <= g->H && sg.ks <= g->W), "tconv: reflect padding wider than the plane");
+    CAT_REQUIRE((int64_t)g->N * g->H * g->W * sg.xcs < (int64_t)4294967295LL, "tconv: source larger than 2^32 elements");
+    hl = sg.padv > hl ? sg.padv : hl;
+    hr = sg.ks - 1 - sg.padv > hr ? sg.ks - 1 - sg.padv : hr;
+    kflops += (double)sg.ks * sg.ks * sg.c4;
+  }
+  static const int tw_env = getenv("CAT_PK_TW") ? atoi(getenv("CAT_PK_TW")) : 0;
+  cat_pk::Launch L;
+  L.nt_total = cat::cdiv(g->Nn, 16);
+  L.nblk = cat::cdiv(L.nt_total, 8);
+  const int nt = cat::cdiv(L.nt_total, L.nblk);
+  L.nblk = cat::cdiv(L.nt_total, nt);
+  // 8 x 16 pixel tiles unless that makes a very large grid (then 8 x 32: half the halo traffic, twice the filter reuse per wave)
+  const int64_t wg16 = (int64_t)g->N * cat::cdiv(g->Ho, 8) * cat::cdiv(g->Wo, 16) * L.nblk;
+  const int tw = tw_env ? tw_env : (wg16 >= 4096 ? 32 : 16);
+  CAT_REQUIRE(tw == 16 || tw == 32, "tconv: CAT_PK_TW must be 16 or 32");
+  L.hl = hl;
+  L.tr = cat_pk::TH + hl + hr;
+  L.tc = tw + hl + hr;
+  L.tiles_x = cat::cdiv(g->Wo, tw);
+  L.tiles = L.tiles_x * cat::cdiv(g->Ho, cat_pk::TH);
+  const int64_t grid = (int64_t)g->N * L.tiles * L.nblk;
+  CAT_REQUIRE(grid < (int64_t)2147483647, "tconv: grid too large");
+  const size_t lds = (size_t)2 * L.tr * L.tc * cat_pk::PITCH * sizeof(float) + 2 * cat_pk::TABN * sizeof(int);
+  hipStream_t s = (hipStream_t)stream;
+  cat::ProfScope prof(g->nseg > 1 ? "conv_tconv_multi" : "conv_tconv", 2.0 * (double)g->N * g->Ho * g->Wo * g->Nn * kflops, 0.0, stream);
+#define CAT_PK_LAUNCH(NT, TW)                                                                                              \
+  {                                                                                                                        \
+    static bool attr_set = false;                                                                                          \
+    if (!attr_set) {                                                                                                       \
+      (void)hipFuncSetAttribute((const void*)cat_pk::tconv_kernel<NT, TW>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \
+      attr_set = true;                                                                                                     \
+    }                                                                                                                      \
+    cat_pk::tconv_kernel<NT, TW><<<(int)grid, 256, lds, s>>>(*g, pack, bias, y, L);                                        \
+  }
+#define CAT_PK_NT(TW)                          \
+  switch (nt) {                                \
+    case 1: CAT_PK_LAUNCH(1, TW) break;        \
+    case 2: CAT_PK_LAUNCH(2, TW) break;        \
+    case 3: CAT_PK_LAUNCH(3, TW) break;        \
+    case 4: CAT_PK_LAUNCH(4, TW) break;        \
+    case 5: CAT_PK_LAUNCH(5, TW) break;        \
+    case 6: CAT_PK_LAUNCH(6, TW) break;        \
+    case 7: CAT_PK_LAUNCH(7, TW) break;        \
+    default: CAT_PK_LAUNCH(8, TW) break;       \
+  }
+  if (tw == 16) { CAT_PK_NT(16) } else { CAT_PK_NT(32) }
+#undef CAT_PK_NT
+#undef CAT_PK_LAUNCH
+  return cat::check_launch("tconv_fwd");
+}
+
+}  // extern "C"

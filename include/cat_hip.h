@@ -237,6 +237,44 @@ int cat_spectral_norm_fwd(const float* w, int O, int I, int taps, int wcs, float
 int cat_spectral_norm_bwd(const float* gw, const float* w_sn, const float* u, const float* vp, const float* sigma,
                           int O, int taps, int wcs, float* dw, int accumulate, void* ws, cat_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * LDS-tile convolution with pre-packed filters, stride 1, k in {1,3,5} (csrc/conv_pk.hip):
+ *   out[n][oy][ox][co] = act(bias[co] + sum_s sum_(ky,kx) sum_c f_s(src_s[n][oy-padv_s+ky][ox-padv_s+kx][c]) * W_s(tap,c,co))
+ * One launch = a single nn.Conv2d (+ the nn.ReflectionPad2d in front of it), its input gradient, or the K-concatenated SUM of up to
+ * 8 convolutions of different kernel sizes over different tensors: the branch sum of InvertedResidualChannels.forward
+ * (models/modules/inception_modules.py:230-236: sum_k res_k(x) + sum_k dw_k(x)) written once, and in the backward pass the sum of the
+ * branches' first-conv input gradients.  f_s = optional per-channel affine + activation applied while the source tile is staged
+ * (the normalise + ReLU of a train-mode norm_layer, inception_modules.py:43-44, folded into the conv that consumes it).
+ * Filters are consumed from a packed stream (cat_tconv_pack) in the exact order of the kernel's MFMA groups; trainable layers
+ * re-pack once per optimizer step. */
+#define CAT_TCONV_MAXSEG 8
+typedef struct {
+  const float* src;    /* [N][H][W][xcs], pointing at the segment's first channel (a channel slice of a wider buffer is fine) */
+  const float* scale;  /* optional [c4] staging affine: v = act(src * scale + shift); NULL = none (act still applies) */
+  const float* shift;
+  int xcs, c4;         /* pixel stride of src, channels of this segment (multiple of 4; padding channels must read as 0 after f_s) */
+  int ks, padv;        /* ks x ks taps; output pixel (oy, ox) reads src pixel (oy - padv + ky, ox - padv + kx) */
+  int act;             /* CAT_ACT_* applied while staging */
+  float slope;
+  int reflect;         /* source pixels outside the plane: 1 = mirrored (nn.ReflectionPad2d), 0 = zero */
+  int pack_off;        /* float offset of this segment's packed filters inside `pack` */
+} cat_tseg_t;
+typedef struct {
+  int N, H, W;         /* source planes (all segments) */
+  int Ho, Wo;          /* output plane */
+  int Nn, ycs, ycw;    /* output channels, pixel stride, channels [Nn, ycw) are written as 0 */
+  int act;             /* epilogue activation */
+  float slope;
+  int nseg;
+  cat_tseg_t seg[CAT_TCONV_MAXSEG];
+} cat_tconv_t;
+/* floats of packed filters for one segment (ks, c4) and Nn output channels */
+size_t cat_tconv_pack_floats(int ks, int c4, int Nn);
+/* mode 0 (forward):  W(tap, c, n) = w[n*wn + tap*wcs + c],  w = [Nn][ks*ks][wcs] conv weight, Ck = valid input channels
+ * mode 1 (dgrad):    W(tap, c, n) = w[c*wn + (ks*ks-1-tap)*wcs + n], w = [Ck][ks*ks][wcs] conv weight (Ck = its Cout, Nn = its Cin) */
+int cat_tconv_pack(const float* w, int mode, int Nn, int Ck, int ks, int wcs, int wn, int c4, float* dst, cat_stream_t stream);
+int cat_tconv_fwd(const cat_tconv_t* g, const float* pack, const float* bias, float* y, cat_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
