@@ -28,12 +28,12 @@ TCONV_MAXSEG = 8
 
 
 class TSeg(C.Structure):
-    _fields_ = [('src', c_p), ('scale', c_p), ('shift', c_p), ('xcs', c_i), ('c4', c_i), ('ks', c_i), ('padv', c_i), ('act', c_i),
+    _fields_ = [('src', c_p), ('scale', c_p), ('shift', c_p), ('xcs', c_i), ('c4', c_i), ('cin', c_i), ('ks', c_i), ('padv', c_i), ('act', c_i),
                 ('slope', c_f), ('reflect', c_i), ('pack_off', c_i)]
 
 
 class TConv(C.Structure):
-    _fields_ = [(n, c_i) for n in ('N', 'H', 'W', 'Ho', 'Wo', 'Nn', 'ycs', 'ycw', 'act')] + [('slope', c_f), ('nseg', c_i),
+    _fields_ = [('res', c_p)] + [(n, c_i) for n in ('rcs', 'N', 'H', 'W', 'Ho', 'Wo', 'Nn', 'ycs', 'ycw', 'act')] + [('slope', c_f), ('nseg', c_i),
                                                                                             ('seg', TSeg * TCONV_MAXSEG)]
 
 
@@ -66,7 +66,7 @@ SIGNATURES = {
     'cat_channel_sum': (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p]),
     'cat_channel_sum_ws_bytes': (C.c_size_t, [c_i, c_i]),
     'cat_norm_ws_bytes': (C.c_size_t, [_NG]),
-    'cat_norm_fwd': (c_i, [_NG, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    'cat_norm_fwd': (c_i, [_NG, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     'cat_norm_bwd': (c_i, [_NG, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p]),
     'cat_bn_fold': (c_i, [c_p, c_p, c_p, c_p, c_f, c_i, c_p, c_p, c_p]),
     'cat_affine_act_fwd': (c_i, [c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_f, c_p]),

@@ -270,8 +270,13 @@ __global__ __launch_bounds__(256) void tconv_kernel(const cat_tconv_t g, const f
       for (int j = 0; j < NT; ++j) {
         const int co = (j0 + j) * 16 + lr;
         if (j0 + j >= L.nt_total) continue;
-        if (co < g.Nn) yo[co] = cat::apply_act(acc[i][j][rg] + (bias ? bias[co] : 0.f), g.act, g.slope);
-        else if (co < g.ycw) yo[co] = 0.f;
+        if (co < g.Nn) {
+          float v = cat::apply_act(acc[i][j][rg] + (bias ? bias[co] : 0.f), g.act, g.slope);
+          if (g.res) v += g.res[(((int64_t)n * g.Ho + oy) * g.Wo + ox) * g.rcs + co];
+          yo[co] = v;
+        } else if (co < g.ycw) {
+          yo[co] = 0.f;
+        }
       }
     }
   }
@@ -342,6 +347,7 @@ int cat_tconv_fwd(const cat_tconv_t* g, const float* pack, const float* bias, fl
   CAT_REQUIRE(g->nseg >= 1 && g->nseg <= CAT_TCONV_MAXSEG, "tconv: %d segments", g->nseg);
   CAT_REQUIRE(g->N > 0 && g->H > 0 && g->W > 0 && g->Ho > 0 && g->Wo > 0 && g->Nn > 0, "tconv: empty geometry");
   CAT_REQUIRE((g->ycs & 3) == 0 && g->ycs >= g->Nn && g->ycw <= g->ycs, "tconv: bad output stride");
+  CAT_REQUIRE(g->res == nullptr || g->rcs >= g->Nn, "tconv: residual stride");
   int hl = 0, hr = 0;
   double kflops = 0.0;
   for (int s = 0; s < g->nseg; ++s) {
@@ -354,7 +360,8 @@ int cat_tconv_fwd(const cat_tconv_t* g, const float* pack, const float* bias, fl
     CAT_REQUIRE((int64_t)g->N * g->H * g->W * sg.xcs < (int64_t)4294967295LL, "tconv: source larger than 2^32 elements");
     hl = sg.padv > hl ? sg.padv : hl;
     hr = sg.ks - 1 - sg.padv > hr ? sg.ks - 1 - sg.padv : hr;
-    kflops += (double)sg.ks * sg.ks * sg.c4;
+    CAT_REQUIRE(sg.cin > 0 && sg.cin <= sg.c4, "tconv: segment %d valid channel count", s);
+    kflops += (double)sg.ks * sg.ks * sg.cin;
   }
   static const int tw_env = getenv("CAT_PK_TW") ? atoi(getenv("CAT_PK_TW")) : 0;
   cat_pk::Launch L;

@@ -109,10 +109,12 @@ __global__ __launch_bounds__(256) void norm_fwd_finalize_kernel(const float* __r
                                                                 float* __restrict__ save_mean, float* __restrict__ save_rstd,
                                                                 float* __restrict__ running_mean, float* __restrict__ running_var,
                                                                 float* __restrict__ scale, float* __restrict__ shift, int G, int Pg,
-                                                                int C, int cs, int nb, float eps, float momentum) {
+                                                                int C, int cs, int nb, float eps, float momentum,
+                                                                int64_t* __restrict__ num_batches) {
   // grid (cdiv(cs,4), G); one WAVE per channel: 64 lanes stride over the nb partial blocks, wave-shuffle reduce (the serial
   // 64-channels x 4-lanes version cost 55 us at nb = 1024 -- more than the stats pass it finishes)
   const int g = blockIdx.y, c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (num_batches && blockIdx.x == 0 && g == 0 && threadIdx.x == 0) *num_batches += 1;   // nn.BatchNorm2d.num_batches_tracked
   if (c >= cs) return;
   const int idx = g * cs + c;
   if (c >= C) {
@@ -290,7 +292,8 @@ extern "C" {
 size_t cat_norm_ws_bytes(const cat_norm_t* g) { return plan(g).bytes; }
 
 int cat_norm_fwd(const cat_norm_t* g, const float* x, const float* gamma, const float* beta, float* y, float* save_mean,
-                 float* save_rstd, float* running_mean, float* running_var, void* ws, cat_stream_t stream) {
+                 float* save_rstd, float* running_mean, float* running_var, int64_t* num_batches_tracked, void* ws,
+                 cat_stream_t stream) {
   CAT_REQUIRE(g->cs % 4 == 0 && g->cs >= g->C && g->N > 0 && g->HW > 0, "norm: bad geometry");
   CAT_REQUIRE(ws && save_mean && save_rstd, "norm fwd: workspace / save buffers required");
   cat::ProfScope prof("norm_fwd", 0.0, 3 * 4.0 * (double)g->N * g->HW * g->cs, stream);
@@ -302,7 +305,8 @@ int cat_norm_fwd(const cat_norm_t* g, const float* x, const float* gamma, const 
   norm_fwd_finalize_kernel<<<dim3(cdiv(g->cs, 4), p.G), 256, 0, s>>>(x, w + p.part_off, gamma, beta, save_mean, save_rstd,
                                                                    g->mode == CAT_NORM_BATCH ? running_mean : nullptr,
                                                                    g->mode == CAT_NORM_BATCH ? running_var : nullptr, w + p.scale_off,
-                                                                   w + p.shift_off, p.G, p.Pg, g->C, g->cs, p.nb, g->eps, g->momentum);
+                                                                   w + p.shift_off, p.G, p.Pg, g->C, g->cs, p.nb, g->eps, g->momentum,
+                                                                   g->mode == CAT_NORM_BATCH ? num_batches_tracked : nullptr);
   const int64_t nquads = (int64_t)g->N * g->HW * p.nq;
   if (idx32(nquads))
     norm_apply_kernel<int><<<ew_grid(nquads), 256, 0, s>>>(x, w + p.scale_off, w + p.shift_off, y, (int)nquads, p.nq, p.Pg * p.nq, g->cs,

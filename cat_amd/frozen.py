@@ -11,8 +11,9 @@ collapses algebraically -- same values, different evaluation order -- into
     dw  three depthwise convs (+ BN + ReLU in the epilogue) reading / writing channel SLICES of the concatenated buffers
     F   one 1x1 conv  [h_res1 | h_dw1 | h_dw3 | h_dw5] -> C  (the four 42->256 convs as ONE GEMM with K = 176; pw_bn's scale folded
         into its weights, every bias of the block and pw_bn's shift folded into its bias)
-    k>1 res branches keep their two convs (first + BN + ReLU folded; second with pw_bn's scale folded in)
-    out = add_n(x, F, k3, k5)
+    k>1 res branches keep their first conv (+ BN + ReLU folded); their second convs (pw_bn's scale folded in), F and the skip
+    connection become ONE K-concatenated LDS-tile launch (csrc/conv_pk.hip): out = x + [h | hid3 | hid5] * [F ; W3 ; W5] + bias,
+    written once -- on planes too small for that kernel: out = add_n(x, F, k3, k5)
 
 instead of 12 convs + 3 activations + add_n(6) + affine + add_n(2): the 42->256 1x1 layers were epilogue-bound (K = 44: 27 TFLOP/s),
 and 10 of 18 full-size tensor passes disappear.  One-time weight folding is cached per block (invalidated when a tensor changes).
@@ -117,7 +118,14 @@ def _plan(block):
             b_f += last.bias.detach() * s_pw
         wides.append(dict(op=op, w2=w2, k=last.kernel_size[0]))
     act, slope = cnn._act_code(act_mod)
-    plan = dict(key=key, hc=hc, w_a=w_a, b_a=b_a.contiguous(), w_f=w_f, b_f=b_f.contiguous(), dws=dws, wides=wides, act=act, slope=slope,
+    # packed filters of the fused tail: segment 0 = F (1x1 over the concatenated hidden buffer), then one segment per wide branch
+    from . import tconv
+    packs = [tconv.pack(w_f, tconv.FWD)] + [tconv.pack(wd['w2'], tconv.FWD) for wd in wides]
+    pack_offs, po = [], 0
+    for pk in packs:
+        pack_offs.append(po)
+        po += pk.numel()
+    plan = dict(key=key, tail_pack=torch.cat(packs), tail_offs=pack_offs, hc=hc, w_a=w_a, b_a=b_a.contiguous(), w_f=w_f, b_f=b_f.contiguous(), dws=dws, wides=wides, act=act, slope=slope,
                 pad_mode=pad_mode, copies=[(o, sz) for (kind, _), (o, m, sz) in zip(slots, offs) if kind == 'res'])
     block._cat_frozen = plan
     return plan
@@ -141,6 +149,8 @@ def block_forward(block, x):
             g = ops._conv_geom(n, h, w, d['m'], hc, h, w, d['m'], hc, d['k'], d['k'], 1, d['pad'], p['pad_mode'], p['act'], p['slope'], d['sz'])
             L.call('cat_dwconv2d_fwd', C.byref(g), C.c_void_p(hbuf.data_ptr() + 4 * d['off']), ops._p(d['w']), ops._p(d['b']),
                    C.c_void_p(h2.data_ptr() + 4 * d['off']), stc)
+        if fused_tail:
+            return h2
         # F: every last 1x1 conv as one GEMM (pw_bn scale in the weights; all biases + pw_bn shift in the bias)
         return ops.Conv2dFn.apply(h2, p['w_f'], p['b_f'], 1, 0, L.PAD_ZERO, L.ACT_NONE, 0.0)
 
@@ -148,12 +158,23 @@ def block_forward(block, x):
         def run(xi):
             op = wd['op']
             hid = op[1](op[0](xi))      # pad -> conv k x k with folded BN + activation (FusedSequential's frozen path)
+            if fused_tail:
+                return hid
             return ops.Conv2dFn.apply(hid, wd['w2'], None, 1, (wd['k'] - 1) // 2, p['pad_mode'], L.ACT_NONE, 0.0)
         return run
 
+    fused_tail = ops.tconv_applicable(n, h, w, c, 3, 3, 1, 1) and 1 + len(p['wides']) <= L.TCONV_MAXSEG
     fns = [concat_chain] + [wide_chain(wd) for wd in p['wides']]
     if ops.branch_streams_enabled() and len(fns) > 1:
         outs = ops.run_on_side_streams(fns, [x] * len(fns))
     else:
         outs = [fn(x) for fn in fns]
-    return ops.AddNFn.apply(x, *outs)
+    if not fused_tail:
+        return ops.AddNFn.apply(x, *outs)
+    from . import tconv
+    refl = p['pad_mode'] == L.PAD_REFLECT
+    segs = [tconv.Segment(outs[0], 1, 0, False, p['tail_offs'][0])]
+    for wd, hid, off in zip(p['wides'], outs[1:], p['tail_offs'][1:]):
+        segs.append(tconv.Segment(hid, wd['k'], (wd['k'] - 1) // 2, refl, off))
+    y = ops.empty_act(n, c, h, w, x.device)
+    return tconv.run(segs, p['tail_pack'], p['b_f'], y, c, n, h, w, h, w, res=x)

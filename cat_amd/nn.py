@@ -199,15 +199,15 @@ class _NormMixin:
             raise NotImplementedError('padding in front of a norm layer')
         act, slope = _act_code(fuse_act)
         if use_batch_stats:
-            rm = rv = None
+            rm = rv = nbt = None
             if mode == L.NORM_BATCH and self.training and self.track_running_stats:
                 rm, rv = self.running_mean, self.running_var
                 if self.momentum is None:
                     raise NotImplementedError('cumulative-average BatchNorm (momentum=None)')
-                if count_batches:
-                    self.num_batches_tracked.add_(1)
+                if count_batches:      # bumped by the finalize kernel: no stock torch kernel in the step
+                    nbt = self.num_batches_tracked
             return ops.NormActFn.apply(x, self.weight, self.bias, rm, rv, mode, float(self.eps),
-                                       float(self.momentum if self.momentum is not None else 0.0), act, slope)
+                                       float(self.momentum if self.momentum is not None else 0.0), act, slope, nbt)
         scale, shift = ops.bn_fold(self.weight, self.bias, self.running_mean, self.running_var, float(self.eps))
         return ops.affine_act(x, scale, shift, act, slope)
 

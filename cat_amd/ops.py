@@ -256,6 +256,43 @@ def _nchw(t):
 
 
 # ---------------------------------------------------------------------------------------------- convolutions
+_TCONV = os.environ.get('CAT_TCONV', '1') != '0'      # LDS-tile kernels with packed filters for stride-1 3x3 / 5x5 layers (A/B switch)
+
+
+def tconv_applicable(n, h, w, cout, kh, kw, stride, pad):
+    """Stride-1 "same" 3x3 / 5x5 convolutions with enough output tiles to fill the chip go through csrc/conv_pk.hip (forward and
+    input gradient); tiny planes (the SPADE generators' 4x8 .. 16x32 stages) keep the split-K im2col kernels, Cout <= 3 the direct ones."""
+    if not _TCONV or stride != 1 or kh != kw or kh not in (3, 5) or pad != (kh - 1) // 2 or cout <= 3:
+        return False
+    return n * ((h + 7) // 8) * ((w + 15) // 16) >= 96
+
+
+def packed_filter(weight, wcl, mode):
+    """The conv weight in the MFMA-group order cat_tconv_fwd consumes, cached on the tensor and re-packed (in place) when the
+    weight changed: torch's version counter for ordinary tensors, the optimizer epoch for FusedAdam-owned parameters (updated
+    through raw pointers).  One ~2 us launch per layer and direction per step."""
+    from . import optim, tconv
+    owner = weight if weight is not None else wcl
+    if owner is not wcl and owner.data_ptr() != wcl.data_ptr():      # a re-laid-out temporary (foreign layout): nothing to key a cache on
+        return tconv.pack(wcl, mode)
+    trainable = getattr(owner, '_cat_grad_view', None) is not None
+    key = (wcl.data_ptr(), wcl._version, optim.weights_epoch() if trainable else -1)
+    cache = getattr(owner, '_cat_pk', None)
+    if cache is None:
+        cache = owner._cat_pk = {}
+    ent = cache.get(mode)
+    if ent is not None and ent[0] == key:
+        return ent[1]
+    if ent is None or ent[1].device != wcl.device:
+        o, i, kh, kw = wcl.shape
+        nn, ck = (o, i) if mode == tconv.FWD else (i, o)
+        ent = [None, torch.empty(tconv.pack_floats(kh, tconv.cs4(ck), nn), device=wcl.device, dtype=torch.float32)]
+        cache[mode] = ent
+    tconv.pack_into(ent[1], wcl, mode)
+    ent[0] = key
+    return ent[1]
+
+
 def _conv_fwd(g, x, w, bias, y, st):
     """cat_conv2d_fwd, or its split-K variant when the layer's tile grid is too small for the chip."""
     nb = L.query('cat_conv2d_fwd_ws_bytes', C.byref(g))
@@ -288,8 +325,13 @@ class Conv2dFn(torch.autograd.Function):
         ho = (h + 2 * pad - kh) // stride + 1
         wo = (w + 2 * pad - kw) // stride + 1
         y = empty_act(n, cout, ho, wo, x.device)
-        g = _conv_geom(n, h, w, cin, act_cs(x), ho, wo, cout, act_cs(y), kh, kw, stride, pad, pad_mode, act, slope, act_cs(y), wcs)
-        _conv_fwd(g, x, wcl, bias, y, _stream())
+        if tconv_applicable(n, h, w, cout, kh, kw, stride, pad):
+            from . import tconv
+            pk = packed_filter(weight, wcl, tconv.FWD)
+            tconv.run([tconv.Segment(x, kh, pad, pad_mode == L.PAD_REFLECT, 0)], pk, bias, y, cout, n, h, w, ho, wo, act, slope)
+        else:
+            g = _conv_geom(n, h, w, cin, act_cs(x), ho, wo, cout, act_cs(y), kh, kw, stride, pad, pad_mode, act, slope, act_cs(y), wcs)
+            _conv_fwd(g, x, wcl, bias, y, _stream())
         ctx.geom = (n, h, w, cin, act_cs(x), ho, wo, cout, act_cs(y), kh, kw, stride, pad, pad_mode, wcs)
         ctx.act, ctx.slope = act, slope
         ctx.weight, ctx.bias = weight, bias
@@ -307,14 +349,24 @@ class Conv2dFn(torch.autograd.Function):
         st = _stream()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
+            tile = tconv_applicable(n, h, w, cin, kh, kw, stride, pad)
+            if tile:
+                from . import tconv
+                pk = packed_filter(ctx.weight, wcl, tconv.DGRAD)
             if pad_mode == L.PAD_REFLECT and pad > 0:
                 dxp = empty_act(n, cin, h + 2 * pad, w + 2 * pad, x.device)
-                _conv_dgrad(g, dy, wcl, None, dxp, act_cs(dxp), act_cs(dxp), st)
+                if tile:   # gradient of the PADDED plane: full correlation of dy with the flipped filters
+                    tconv.run([tconv.Segment(dy, kh, kh - 1, False, 0)], pk, None, dxp, cin, n, ho, wo, h + 2 * pad, w + 2 * pad)
+                else:
+                    _conv_dgrad(g, dy, wcl, None, dxp, act_cs(dxp), act_cs(dxp), st)
                 dx = empty_act(n, cin, h, w, x.device)
                 L.call('cat_reflect_pad_bwd', _p(dxp), _p(dx), n, h, w, cin, act_cs(dx), pad, st)
             else:
                 dx = empty_act(n, cin, h, w, x.device)
-                _conv_dgrad(g, dy, wcl, None, dx, act_cs(dx), act_cs(dx), st)
+                if tile:
+                    tconv.run([tconv.Segment(dy, kh, kh - 1 - pad, False, 0)], pk, None, dx, cin, n, ho, wo, h, w)
+                else:
+                    _conv_dgrad(g, dy, wcl, None, dx, act_cs(dx), act_cs(dx), st)
         if ctx.needs_input_grad[1]:
             ws = workspace(L.query('cat_conv2d_wgrad_ws_bytes', C.byref(g)), x.device)
 
@@ -445,7 +497,7 @@ class NormActFn(torch.autograd.Function):
     """InstanceNorm2d / BatchNorm2d with batch statistics, fused with the activation behind it."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, mode, eps, momentum, act, slope):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, mode, eps, momentum, act, slope, num_batches=None):
         _require_cuda(x)
         x = conform(x)
         n, c, h, w = x.shape
@@ -457,7 +509,7 @@ class NormActFn(torch.autograd.Function):
         rstd = torch.empty((groups, c), device=x.device, dtype=torch.float32)
         ws = workspace(L.query('cat_norm_ws_bytes', C.byref(g)), x.device)
         L.call('cat_norm_fwd', C.byref(g), _p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), _p(running_mean), _p(running_var),
-               _p(ws), _stream())
+               _p(num_batches), _p(ws), _stream())
         ctx.geom = (n, h * w, c, cs, mode, eps, momentum, act, slope)
         ctx.gamma, ctx.beta = gamma, beta
         ctx.save_for_backward(x, mean, rstd, gamma, beta)
@@ -493,7 +545,7 @@ class NormActFn(torch.autograd.Function):
             dbeta = torch.empty_like(beta) if need_b else None
             L.call('cat_norm_bwd', C.byref(g), _p(x), _p(dy), _p(gamma), _p(beta), _p(mean), _p(rstd), _p(dx), _p(dgamma), _p(dbeta), 0,
                    _p(ws), st)
-        return dx, dgamma, dbeta, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
 def affine_act(x, scale, shift, act, slope):

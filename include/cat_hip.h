@@ -95,7 +95,9 @@ size_t cat_channel_sum_ws_bytes(int M, int cs);
  * biased variance, eps inside the sqrt, BatchNorm running stats use the unbiased variance.
  *   G = number of statistic groups (N for instance norm, 1 for batch norm); each group spans M/G pixels.
  *   save_mean / save_rstd: [G][C] outputs kept for the backward pass.
- *   running_mean / running_var: BatchNorm only, may be NULL.                                   */
+ *   running_mean / running_var: BatchNorm only, may be NULL.
+ *   num_batches_tracked: BatchNorm only, may be NULL; incremented by one on the device (nn.BatchNorm2d's counter), so that no
+ *   stock torch kernel is left in the step.                                                     */
 typedef struct {
   int N, HW, C, cs;
   int mode;          /* CAT_NORM_INSTANCE | CAT_NORM_BATCH */
@@ -105,8 +107,8 @@ typedef struct {
 } cat_norm_t;
 size_t cat_norm_ws_bytes(const cat_norm_t* g);
 int cat_norm_fwd(const cat_norm_t* g, const float* x, const float* gamma, const float* beta, float* y,
-                 float* save_mean, float* save_rstd, float* running_mean, float* running_var, void* ws,
-                 cat_stream_t stream);
+                 float* save_mean, float* save_rstd, float* running_mean, float* running_var,
+                 int64_t* num_batches_tracked, void* ws, cat_stream_t stream);
 /* dx, dgamma (+)=, dbeta (+)= from dy (gradient w.r.t. the activated output), the saved pre-norm input x and
  * the saved statistics.  gamma/dgamma/dbeta may be NULL (affine=False). */
 int cat_norm_bwd(const cat_norm_t* g, const float* x, const float* dy, const float* gamma, const float* beta,
@@ -253,6 +255,7 @@ typedef struct {
   const float* scale;  /* optional [c4] staging affine: v = act(src * scale + shift); NULL = none (act still applies) */
   const float* shift;
   int xcs, c4;         /* pixel stride of src, channels of this segment (multiple of 4; padding channels must read as 0 after f_s) */
+  int cin;             /* valid channels (<= c4): FLOP accounting only */
   int ks, padv;        /* ks x ks taps; output pixel (oy, ox) reads src pixel (oy - padv + ky, ox - padv + kx) */
   int act;             /* CAT_ACT_* applied while staging */
   float slope;
@@ -260,6 +263,8 @@ typedef struct {
   int pack_off;        /* float offset of this segment's packed filters inside `pack` */
 } cat_tseg_t;
 typedef struct {
+  const float* res;    /* optional residual added AFTER the epilogue activation: y = act(acc + bias) + res (the block's skip connection) */
+  int rcs;             /* pixel stride of res */
   int N, H, W;         /* source planes (all segments) */
   int Ho, Wo;          /* output plane */
   int Nn, ycs, ycw;    /* output channels, pixel stride, channels [Nn, ycw) are written as 0 */

@@ -102,6 +102,107 @@ def test_conv2d_fwd_bwd(dev, cin, cout, k, stride, pad, reflect, act, n, h, w):
     assert rel(bg.grad, br.grad) < TOL
 
 
+def _families():
+    import ctypes as C
+    from cat_amd import _lib
+    lib = _lib.load()
+    n = lib.cat_prof_collect()
+    name, cnt, ms, fl = C.create_string_buffer(64), C.c_int64(), C.c_double(), C.c_double()
+    out = {}
+    for i in range(n):
+        lib.cat_prof_family(i, name, 64, C.byref(cnt), C.byref(ms), C.byref(fl))
+        out[name.value.decode()] = cnt.value
+    return out
+
+
+# stride-1 3x3 / 5x5 layers on planes large enough for the LDS-tile kernels with packed filters (csrc/conv_pk.hip): the pruned
+# student's ragged widths, the teacher's 256 <-> 42 pairs, N blocks (Cout > 128), ragged plane edges, zero and reflect padding
+TCONV_CASES = [
+    # cin, cout, k, reflect, act, N, H, W
+    (77, 18, 5, True, 0, 4, 48, 64), (18, 77, 5, True, 0, 4, 48, 64), (77, 12, 3, False, 2, 4, 48, 64), (9, 77, 5, False, 0, 3, 50, 70),
+    (256, 42, 5, True, 0, 4, 56, 64), (42, 256, 3, True, 0, 4, 56, 64), (23, 130, 3, False, 0, 3, 61, 67), (16, 16, 3, True, 3, 4, 48, 64),
+]
+
+
+@pytest.mark.parametrize('cin,cout,k,reflect,act,n,h,w', TCONV_CASES)
+def test_conv2d_lds_tile_fwd_bwd(dev, cin, cout, k, reflect, act, n, h, w):
+    from cat_amd import _lib, ops
+    pad = (k - 1) // 2
+    assert ops.tconv_applicable(n, h, w, cout, k, k, 1, pad)
+    x = detfill.normal((n, cin, h, w), 1)
+    wt = detfill.normal((cout, cin, k, k), 2, 1.0 / np.sqrt(cin * k * k))
+    b = detfill.normal((cout,), 3, 0.1)
+    xr, wr, br = x.clone().requires_grad_(True), wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    xp = F.pad(xr, (pad,) * 4, mode='reflect') if reflect else xr
+    yr = F.conv2d(xp, wr, br, padding=0 if reflect else pad)
+    yr = {0: yr, 2: F.leaky_relu(yr, 0.2), 3: torch.tanh(yr)}[act]
+    gy = detfill.normal(tuple(yr.shape), 4)
+    yr.backward(gy)
+    xg, bg = _nhwc(x, dev, True), b.to(dev).requires_grad_(True)
+    wg = ops.padded_weight_like(wt.shape, dev)
+    wg.copy_(wt)
+    wg.requires_grad_(True)
+    lib = _lib.load()
+    lib.cat_prof_enable(1)
+    y = ops.Conv2dFn.apply(xg, wg, bg, 1, pad, 1 if reflect else 0, act, 0.2)
+    y.backward(_nhwc(gy, dev))
+    torch.cuda.synchronize()
+    fam = _families()
+    lib.cat_prof_enable(0)
+    assert fam.get('conv_tconv', 0) == 2, fam          # forward + input gradient both ran on the LDS-tile kernel
+    assert rel(y, yr) < TOL
+    cs = ops.act_cs(y)
+    full = torch.as_strided(y, (y.shape[0], cs, y.shape[2], y.shape[3]), y.stride())
+    assert cs == cout or float(full[:, cout:].abs().max()) == 0.0
+    assert rel(xg.grad, xr.grad) < TOL
+    assert rel(wg.grad, wr.grad) < TOL
+    assert rel(bg.grad, br.grad) < TOL
+    # a changed weight must be re-packed (the cache keys on torch's version counter / the optimizer epoch)
+    with torch.no_grad():
+        wg.mul_(2.0)
+        y2 = ops.Conv2dFn.apply(xg.detach(), wg, None, 1, pad, 1 if reflect else 0, 0, 0.0)
+        y1 = ops.Conv2dFn.apply(xg.detach(), wg * 0.5, None, 1, pad, 1 if reflect else 0, 0, 0.0)
+    assert rel(y2, 2.0 * y1) < 1e-6
+
+
+@pytest.mark.parametrize('reflect', [True, False])
+def test_tconv_multi_source_branch_sum(dev, reflect):
+    """K-concatenated sum of six convs (k = 1, 3, 5, 1, 1, 1) over channel slices of one hidden buffer, with the normalise + ReLU of
+    the train-mode norm applied while staging: InvertedResidualChannels' branch sum (inception_modules.py:230-236) as one launch."""
+    from cat_amd import _lib as L, ops, tconv
+    n, h, w, cout = 2, 24, 40, 77
+    ms, kss = [11, 12, 18, 15, 15, 12], [1, 3, 5, 1, 1, 1]
+    offs = np.cumsum([0] + [tconv.cs4(m) for m in ms])
+    hc = int(offs[-1])
+    hbuf, sc_all, sh_all = torch.zeros(n, h, w, hc), torch.zeros(hc), torch.zeros(hc)
+    ref = torch.zeros(n, cout, h, w)
+    packs = []
+    for bi, (m, k) in enumerate(zip(ms, kss)):
+        hb = detfill.normal((n, m, h, w), 20 + bi)
+        sc, sh = detfill.normal((m,), 40 + bi).abs() + 0.5, detfill.normal((m,), 60 + bi, 0.3)
+        wt = detfill.normal((cout, m, k, k), 80 + bi, 1.0 / np.sqrt(m * k * k * 6))
+        a = F.relu(hb * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+        p = (k - 1) // 2
+        ref += F.conv2d(F.pad(a, (p,) * 4, mode='reflect') if (reflect and p) else a, wt, None, padding=0 if reflect else p)
+        o = int(offs[bi])
+        hbuf[..., o:o + m] = hb.permute(0, 2, 3, 1)
+        sc_all[o:o + m], sh_all[o:o + m] = sc, sh
+        wg = ops.padded_weight_like(wt.shape, dev)
+        wg.copy_(wt)
+        packs.append(tconv.pack(wg, tconv.FWD))
+    hg, scg, shg = hbuf.to(dev), sc_all.to(dev), sh_all.to(dev)
+    segs, poff = [], 0
+    for bi, (m, k) in enumerate(zip(ms, kss)):
+        o = int(offs[bi])
+        segs.append(tconv.Segment(hg, k, (k - 1) // 2, reflect, poff, c4=tconv.cs4(m), scale=scg[o:], shift=shg[o:], act=L.ACT_RELU, xcs=hc,
+                                  ptr=hg.data_ptr() + 4 * o))
+        poff += packs[bi].numel()
+    b = detfill.normal((cout,), 99, 0.1)
+    y = ops.empty_act(n, cout, h, w, dev)
+    tconv.run(segs, torch.cat(packs), b.to(dev), y, cout, n, h, w, h, w)
+    assert rel(y, ref + b.view(1, -1, 1, 1)) < TOL
+
+
 @pytest.mark.parametrize('cin,cout,n,h,w', [(54, 33, 2, 8, 8), (256, 128, 1, 8, 6), (33, 16, 2, 9, 7), (4, 4, 1, 3, 3)])
 def test_conv_transpose2d(dev, cin, cout, n, h, w):
     from cat_amd import ops
