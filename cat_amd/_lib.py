@@ -28,13 +28,29 @@ TCONV_MAXSEG = 8
 
 
 class TSeg(C.Structure):
-    _fields_ = [('src', c_p), ('scale', c_p), ('shift', c_p), ('xcs', c_i), ('c4', c_i), ('cin', c_i), ('ks', c_i), ('padv', c_i), ('act', c_i),
+    _fields_ = [('src', c_p), ('scale', c_p), ('shift', c_p), ('sstride', c_i), ('xcs', c_i), ('c4', c_i), ('cin', c_i), ('ks', c_i), ('padv', c_i), ('act', c_i),
                 ('slope', c_f), ('reflect', c_i), ('pack_off', c_i)]
 
 
 class TConv(C.Structure):
-    _fields_ = [('res', c_p)] + [(n, c_i) for n in ('rcs', 'N', 'H', 'W', 'Ho', 'Wo', 'Nn', 'ycs', 'ycw', 'act')] + [('slope', c_f), ('nseg', c_i),
+    _fields_ = [('res', c_p), ('stats', c_p)] + [(n, c_i) for n in ('rcs', 'scs', 'N', 'H', 'W', 'Ho', 'Wo', 'Nn', 'ycs', 'ycw', 'nvalid', 'act')] + [('slope', c_f), ('nseg', c_i),
                                                                                             ('seg', TSeg * TCONV_MAXSEG)]
+
+
+TNORM_MAXSLICE, DWM_MAXQ, PREP_MAXSRC = 8, 16, 8
+
+
+class NSlice(C.Structure):
+    _fields_ = [('c0', c_i), ('c', c_i), ('running_mean', c_p), ('running_var', c_p), ('num_batches', c_p)]
+
+
+class DwmGeom(C.Structure):
+    _fields_ = [(n, c_i) for n in ('N', 'H', 'W', 'nq', 'xcs', 'ycs', 'scs', 'sstride', 'reflect', 'act')] + [('slope', c_f), ('ks', c_i * DWM_MAXQ)]
+
+
+class PrepJob(C.Structure):
+    _fields_ = [('srcs', c_p * PREP_MAXSRC), ('dst', c_p)] + [(n, c_i) for n in ('kind', 'nsrc', 'n', 'mode', 'Nn', 'Ck', 'ks', 'wcs', 'wn', 'c4',
+                                                                                'nt_total', 'col0', 'cs', 'block0', 'nblocks')]
 
 
 PAD_ZERO, PAD_REFLECT = 0, 1
@@ -58,6 +74,11 @@ SIGNATURES = {
     'cat_tconv_pack_floats': (C.c_size_t, [c_i, c_i, c_i]),
     'cat_tconv_pack': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
     'cat_tconv_fwd': (c_i, [_TG, c_p, c_p, c_p, c_p]),
+    'cat_tnorm_finalize': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_i, c_p]),
+    'cat_reflect_pad_bwd2': (c_i, [c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    'cat_affine_res_fwd': (c_i, [c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_p]),
+    'cat_dwm_fwd': (c_i, [C.POINTER(DwmGeom), c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    'cat_prep_run': (c_i, [c_p, c_i, c_i, c_i, c_p]),
     'cat_dwconv2d_fwd': (c_i, [_G, c_p, c_p, c_p, c_p, c_p]),
     'cat_dwconv2d_dgrad': (c_i, [_G, c_p, c_p, c_p, c_i, c_p]),
     'cat_dwconv2d_wgrad': (c_i, [_G, c_p, c_p, c_p, c_i, c_p, c_p]),

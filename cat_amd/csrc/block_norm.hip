@@ -1,0 +1,372 @@
+// Train-mode norm layers of an InvertedResidualChannels block WITHOUT their own passes over the activations (gfx950).
+//
+// Reference: models/modules/inception_modules.py:124-180, 230-236 -- every conv of a block is followed by norm_layer + ReLU, i.e.
+// 3 HBM-bound launches (statistics, finalize, apply) per norm and 10 norms per block.  Here
+//   * the producing conv leaves per-tile (sum, sum of squared deviations from the tile mean) behind (cat_tconv_fwd `stats`,
+//     cat_dwm_fwd), for ALL branches of a stage in one concatenated [tile][2][channels] table;
+//   * cat_tnorm_finalize merges the tiles exactly (pairwise / Chan formula: M2 = sum M2_i + sum n_i (mean_i - mean)^2), updates the
+//     running statistics of every branch's norm module and emits scale = gamma * rstd, shift = beta - mean * scale for the whole
+//     concatenation -- one launch per block stage instead of 3 per branch;
+//   * the consumer applies scale / shift + ReLU while it stages its input tile (cat_tconv_fwd segment affine, cat_dwm_fwd), so the
+//     normalised tensor is never written;  cat_affine_res_fwd is the stand-alone apply (y = act(x * scale + shift) [+ residual]) for the
+//     block output and for re-materialising a hidden activation in the backward pass.
+#include "common.h"
+
+namespace {
+using cat::cdiv;
+
+constexpr int TH = 8, TW = 16;
+
+struct FinArgs {
+  cat_nslice_t sl[CAT_TNORM_MAXSLICE];
+  int nsl;
+};
+
+// grid (cdiv(cs, 4), G), one wave per channel; part[((g * tiles + t) * 2 + {0,1}) * scs + c]
+__global__ __launch_bounds__(256) void tnorm_finalize_kernel(const float* __restrict__ part, int scs, int tiles, int tiles_x, int Ho, int Wo,
+                                                             int imgs_per_group, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, FinArgs fa, float eps, float momentum,
+                                                             float* __restrict__ scale, float* __restrict__ shift,
+                                                             float* __restrict__ mean_out, float* __restrict__ rstd_out, int cs,
+                                                             int mstride) {
+  const int g = blockIdx.y, c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (c >= cs) return;
+  // which norm module owns channel c (padding channels between / behind the slices belong to none)
+  int sl = -1;
+  for (int k = 0; k < fa.nsl; ++k)
+    if (c >= fa.sl[k].c0 && c < fa.sl[k].c0 + fa.sl[k].c) sl = k;
+  const int idx = g * cs + c, midx = g * mstride + c;
+  if (sl < 0) {
+    if (lane == 0) {
+      scale[idx] = shift[idx] = 0.f;
+      if (c < mstride) mean_out[midx] = rstd_out[midx] = 0.f;
+    }
+    return;
+  }
+  const int per_img = tiles, ntile = tiles * imgs_per_group;
+  const float* pg = part + (int64_t)g * ntile * 2 * scs + c;
+  float s = 0.f;
+  for (int t = lane; t < ntile; t += 64) s += pg[(int64_t)t * 2 * scs];
+  s = cat::wave_sum(s);
+  const float count = (float)Ho * (float)Wo * (float)imgs_per_group;
+  const float mean = s / count;
+  float m2 = 0.f;
+  for (int t = lane; t < ntile; t += 64) {
+    const int ti = t % per_img;
+    const int ty = ti / tiles_x, tx = ti - ty * tiles_x;
+    const float n = (float)(min(TH, Ho - ty * TH) * min(TW, Wo - tx * TW));
+    const float d = pg[(int64_t)t * 2 * scs] / n - mean;
+    m2 += pg[(int64_t)t * 2 * scs + scs] + n * d * d;
+  }
+  m2 = cat::wave_sum(m2);
+  if (lane != 0) return;
+  float var = m2 / count;
+  var = var > 0.f ? var : 0.f;
+  const float rstd = rsqrtf(var + eps);
+  mean_out[midx] = mean;
+  rstd_out[midx] = rstd;
+  const cat_nslice_t& S = fa.sl[sl];
+  const int cl = c - S.c0;
+  if (S.running_mean) {   // BatchNorm2d.train(): momentum update with the unbiased variance
+    S.running_mean[cl] = (1.f - momentum) * S.running_mean[cl] + momentum * mean;
+    const float unb = count > 1.f ? var * count / (count - 1.f) : var;
+    S.running_var[cl] = (1.f - momentum) * S.running_var[cl] + momentum * unb;
+    if (S.num_batches && cl == 0) *S.num_batches += 1;
+  }
+  const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
+  scale[idx] = ga * rstd;
+  shift[idx] = be - mean * ga * rstd;
+}
+
+// y = act(x * scale[g][c] + shift[g][c]) (+ res): (pixel, quad) walk with 32-bit indices inside a group
+__global__ __launch_bounds__(256) void affine_res_kernel(const float* __restrict__ x, int xcs, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, int sstride, const float* __restrict__ res, int rcs,
+                                                         float* __restrict__ y, int ycs, int Pg, int nq, int act, float slope) {
+  const int g = blockIdx.y;
+  const float* xg = x + (int64_t)g * Pg * xcs;
+  const float* rg = res ? res + (int64_t)g * Pg * rcs : nullptr;
+  float* yg = y + (int64_t)g * Pg * ycs;
+  const unsigned total = (unsigned)Pg * (unsigned)nq;
+  for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const unsigned p = i / (unsigned)nq, q = i - p * (unsigned)nq;
+    const f4 v = *reinterpret_cast<const f4*>(xg + (int64_t)p * xcs + q * 4);
+    const f4 sc = *reinterpret_cast<const f4*>(scale + g * sstride + q * 4);
+    const f4 sh = *reinterpret_cast<const f4*>(shift + g * sstride + q * 4);
+    f4 o = v * sc + sh;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = cat::apply_act(o[e], act, slope);
+    if (rg) o += *reinterpret_cast<const f4*>(rg + (int64_t)p * rcs + q * 4);
+    *reinterpret_cast<f4*>(yg + (int64_t)p * ycs + q * 4) = o;
+  }
+}
+
+// Backward of ReflectionPad2d with separate pixel strides (channel slices of wider buffers) and an optional addend:
+// dx[n,y,x,:] = add[n,y,x,:] + sum of the (up to 3 x 3) padded positions that mirror onto (y, x)
+__global__ __launch_bounds__(256) void reflect_fold2_kernel(const float* __restrict__ dxp, int pcs, float* __restrict__ dx, int dcs,
+                                                            const float* __restrict__ add, int acs, int N, int H, int W, int nq, int pad) {
+  const int64_t total = (int64_t)N * H * W * nq;
+  const int Hp = H + 2 * pad, Wp = W + 2 * pad;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int cq = (int)(i % nq);
+    int64_t r = i / nq;
+    const int64_t pix = r;
+    const int xw = (int)(r % W);
+    r /= W;
+    const int yh = (int)(r % H);
+    const int n = (int)(r / H);
+    int ys[3], xs[3], ny = 0, nx = 0;
+    ys[ny++] = yh + pad;
+    if (yh >= 1 && yh <= pad) ys[ny++] = pad - yh;
+    if (yh <= H - 2 && yh >= H - 1 - pad) ys[ny++] = pad + 2 * (H - 1) - yh;
+    xs[nx++] = xw + pad;
+    if (xw >= 1 && xw <= pad) xs[nx++] = pad - xw;
+    if (xw <= W - 2 && xw >= W - 1 - pad) xs[nx++] = pad + 2 * (W - 1) - xw;
+    f4 s = add ? *reinterpret_cast<const f4*>(add + pix * acs + cq * 4) : f4{0.f, 0.f, 0.f, 0.f};
+    for (int a = 0; a < ny; ++a)
+      for (int b = 0; b < nx; ++b) s += *reinterpret_cast<const f4*>(dxp + (((int64_t)n * Hp + ys[a]) * Wp + xs[b]) * pcs + cq * 4);
+    *reinterpret_cast<f4*>(dx + pix * dcs + cq * 4) = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- depthwise stage of a block
+// All depthwise convs of a block (k = 1 / 3 / 5 per channel quad) in one launch, reading channel slices of the first-stage buffer
+// with that stage's normalise + ReLU applied while the 12 x 20 pixel patch is staged in LDS, writing the concatenated pre-norm output
+// and its per-tile statistics.  One workgroup = 8 x 16 output pixels x all quads; thread = (pixel, quad parity).
+struct DwmArgs {
+  const float* x; const float* scale; const float* shift; const float* w; const float* bias; float* y; float* stats;
+  int xcs, sstride, ycs, scs;
+  int N, H, W, nq, reflect, act;
+  float slope;
+  int tiles_x, tiles;
+  int ks[CAT_DWM_MAXQ];   // kernel size of each channel quad
+};
+
+__global__ __launch_bounds__(256) void dwm_fwd_kernel(DwmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int TR = TH + 4, TC = TW + 4;
+  const int cs = p.nq * 4;
+  float* tile = smem;                    // [TR * TC][cs]
+  float* sw = smem + TR * TC * cs;       // [25][cs] filters in a 5 x 5 frame
+  float* red = sw + 25 * cs;             // [4 waves][cs]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tt = blockIdx.x, n = tt / p.tiles, t = tt - n * p.tiles;
+  const int oy0 = (t / p.tiles_x) * TH, ox0 = (t % p.tiles_x) * TW;
+  const int g = p.sstride ? n : 0;       // per-image statistics (InstanceNorm) or one group
+  for (int i = tid; i < 25 * p.nq; i += 256) *reinterpret_cast<f4*>(sw + i * 4) = *reinterpret_cast<const f4*>(p.w + i * 4);
+  const float neg = p.act == CAT_ACT_RELU ? 0.f : (p.act == CAT_ACT_LRELU ? p.slope : 1.f);
+  for (int i = tid; i < TR * TC * p.nq; i += 256) {
+    const int pix = i / p.nq, q = i - pix * p.nq;
+    const int r = pix / TC, c = pix - r * TC;
+    int iy = oy0 - 2 + r, ix = ox0 - 2 + c;
+    bool v;
+    if (p.reflect) {
+      v = iy > -p.H && iy < 2 * p.H - 1 && ix > -p.W && ix < 2 * p.W - 1;
+      iy = cat::reflect_idx(iy, p.H);
+      ix = cat::reflect_idx(ix, p.W);
+    } else {
+      v = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+    }
+    f4 o = {0.f, 0.f, 0.f, 0.f};
+    if (v) {
+      const f4 xv = *reinterpret_cast<const f4*>(p.x + (((int64_t)n * p.H + iy) * p.W + ix) * p.xcs + q * 4);
+      const f4 sc = *reinterpret_cast<const f4*>(p.scale + g * p.sstride + q * 4);
+      const f4 sh = *reinterpret_cast<const f4*>(p.shift + g * p.sstride + q * 4);
+      o = xv * sc + sh;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = o[e] > 0.f ? o[e] : o[e] * neg;
+    }
+    *reinterpret_cast<f4*>(tile + pix * cs + q * 4) = o;
+  }
+  __syncthreads();
+  const int px = tid & 127, half = tid >> 7;
+  const int py = px >> 4, pxx = px & 15;
+  const bool pv = oy0 + py < p.H && ox0 + pxx < p.W;
+  const int cnt = min(TH, p.H - oy0) * min(TW, p.W - ox0);
+  constexpr int MAXH = CAT_DWM_MAXQ / 2;
+  f4 out[MAXH];
+#pragma unroll
+  for (int k = 0; k < MAXH; ++k) {
+    const int q = half + 2 * k;
+    out[k] = f4{0.f, 0.f, 0.f, 0.f};
+    if (q < p.nq) {
+      const int ks = p.ks[q], o = 2 - (ks >> 1);
+      f4 a = p.bias ? *reinterpret_cast<const f4*>(p.bias + q * 4) : f4{0.f, 0.f, 0.f, 0.f};
+      for (int ky = 0; ky < ks; ++ky)
+        for (int kx = 0; kx < ks; ++kx)
+          a += *reinterpret_cast<const f4*>(tile + ((py + o + ky) * TC + pxx + o + kx) * cs + q * 4) *
+               *reinterpret_cast<const f4*>(sw + ((o + ky) * 5 + o + kx) * cs + q * 4);
+      out[k] = a;
+      if (pv) *reinterpret_cast<f4*>(p.y + (((int64_t)n * p.H + oy0 + py) * p.W + ox0 + pxx) * p.ycs + q * 4) = a;
+    }
+  }
+  if (!p.stats) return;
+  // tile statistics: wave shuffle over its 64 pixels, the two waves of a quad parity through LDS; two passes (sum, then M2)
+  float* dst = p.stats + (int64_t)tt * 2 * p.scs;
+  f4 mean[MAXH];
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+    for (int k = 0; k < MAXH; ++k) {
+      const int q = half + 2 * k;
+      if (q < p.nq) {
+        f4 v = out[k];
+        if (pass == 1) {
+          v = v - mean[k];
+          v = v * v;
+        }
+        if (!pv) v = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = cat::wave_sum(v[e]);
+        if (lane == 0) *reinterpret_cast<f4*>(red + wave * cs + q * 4) = v;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < MAXH; ++k) {
+      const int q = half + 2 * k;
+      if (q < p.nq) {
+        const f4 tot = *reinterpret_cast<const f4*>(red + (2 * half) * cs + q * 4) + *reinterpret_cast<const f4*>(red + (2 * half + 1) * cs + q * 4);
+        if (pass == 0) mean[k] = tot / (float)cnt;
+        if ((tid & 127) == 0) *reinterpret_cast<f4*>(dst + pass * p.scs + q * 4) = tot;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int cat_tnorm_finalize(const float* part, int scs, int G, int N, int Ho, int Wo, const float* gamma, const float* beta, int nslices,
+                       const cat_nslice_t* slices, float eps, float momentum, float* scale, float* shift, float* mean, float* rstd,
+                       int mstride, cat_stream_t stream) {
+  CAT_REQUIRE(G == 1 || G == N, "tnorm finalize: groups must be 1 (batch norm) or N (instance norm)");
+  CAT_REQUIRE(nslices >= 1 && nslices <= CAT_TNORM_MAXSLICE && (scs & 3) == 0, "tnorm finalize: %d slices", nslices);
+  FinArgs fa{};
+  fa.nsl = nslices;
+  for (int k = 0; k < nslices; ++k) {
+    fa.sl[k] = slices[k];
+    CAT_REQUIRE(slices[k].c0 >= 0 && slices[k].c > 0 && slices[k].c0 + slices[k].c <= scs, "tnorm finalize: slice %d outside the table", k);
+  }
+  const int tiles_x = cdiv(Wo, TW), tiles = tiles_x * cdiv(Ho, TH);
+  tnorm_finalize_kernel<<<dim3(cdiv(scs, 4), G), 256, 0, (hipStream_t)stream>>>(part, scs, tiles, tiles_x, Ho, Wo, G == 1 ? N : 1, gamma, beta, fa,
+                                                                                  eps, momentum, scale, shift, mean, rstd, scs, mstride);
+  return cat::check_launch("tnorm_finalize");
+}
+
+int cat_affine_res_fwd(const float* x, int xcs, const float* scale, const float* shift, int sstride, const float* res, int rcs, float* y,
+                       int ycs, int G, int Pg, int C4, int act, float slope, cat_stream_t stream) {
+  CAT_REQUIRE((xcs & 3) == 0 && (ycs & 3) == 0 && (C4 & 3) == 0 && C4 <= xcs && C4 <= ycs, "affine_res: channel layout");
+  CAT_REQUIRE((int64_t)Pg * (C4 / 4) < (int64_t)4000000000LL, "affine_res: group too large");
+  cat::ProfScope prof("affine_res", 0.0, (res ? 12.0 : 8.0) * (double)G * Pg * C4, stream);
+  int64_t b = ((int64_t)Pg * (C4 / 4) + 255) / 256;
+  const int gx = (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+  affine_res_kernel<<<dim3(gx, G), 256, 0, (hipStream_t)stream>>>(x, xcs, scale, shift, sstride, res, rcs, y, ycs, Pg, C4 / 4, act, slope);
+  return cat::check_launch("affine_res");
+}
+
+int cat_reflect_pad_bwd2(const float* dxp, int pcs, float* dx, int dcs, const float* add, int acs, int N, int H, int W, int C4, int pad,
+                         cat_stream_t stream) {
+  CAT_REQUIRE((pcs & 3) == 0 && (dcs & 3) == 0 && (C4 & 3) == 0 && C4 <= pcs && C4 <= dcs && pad < H && pad < W && (!add || C4 <= acs),
+              "reflect_pad_bwd2: bad geometry");
+  cat::ProfScope prof("reflect_pad_bwd", 0.0, 8.0 * N * H * W * C4, stream);
+  const int64_t total = (int64_t)N * H * W * (C4 / 4);
+  int64_t b = (total + 255) / 256;
+  reflect_fold2_kernel<<<(int)(b < 1 ? 1 : (b > 8192 ? 8192 : b)), 256, 0, (hipStream_t)stream>>>(dxp, pcs, dx, dcs, add, acs, N, H, W, C4 / 4, pad);
+  return cat::check_launch("reflect_pad_bwd2");
+}
+
+int cat_dwm_fwd(const cat_dwm_t* g, const float* x, const float* scale, const float* shift, const float* w25, const float* bias, float* y,
+                float* stats, cat_stream_t stream) {
+  CAT_REQUIRE(g->nq >= 1 && g->nq <= CAT_DWM_MAXQ, "dwm: %d channel quads (max %d)", g->nq, CAT_DWM_MAXQ);
+  CAT_REQUIRE((g->xcs & 3) == 0 && (g->ycs & 3) == 0 && g->xcs >= 4 * g->nq && g->ycs >= 4 * g->nq, "dwm: channel layout");
+  CAT_REQUIRE(!g->reflect || (g->H > 2 && g->W > 2), "dwm: reflect padding wider than the plane");
+  DwmArgs a{};
+  a.x = x; a.scale = scale; a.shift = shift; a.w = w25; a.bias = bias; a.y = y; a.stats = stats;
+  a.xcs = g->xcs; a.sstride = g->sstride; a.ycs = g->ycs; a.scs = g->scs;
+  a.N = g->N; a.H = g->H; a.W = g->W; a.nq = g->nq; a.reflect = g->reflect; a.act = g->act; a.slope = g->slope;
+  a.tiles_x = cdiv(g->W, TW);
+  a.tiles = a.tiles_x * cdiv(g->H, TH);
+  for (int q = 0; q < g->nq; ++q) {
+    CAT_REQUIRE(g->ks[q] == 1 || g->ks[q] == 3 || g->ks[q] == 5, "dwm: kernel size %d", g->ks[q]);
+    a.ks[q] = g->ks[q];
+  }
+  const int cs = g->nq * 4;
+  const size_t lds = (size_t)((TH + 4) * (TW + 4) * cs + 25 * cs + 4 * cs) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)dwm_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    attr_set = true;
+  }
+  double taps = 0.0;
+  for (int q = 0; q < g->nq; ++q) taps += 4.0 * g->ks[q] * g->ks[q];
+  cat::ProfScope prof("dwconv_fwd", 2.0 * (double)g->N * g->H * g->W * taps, 0.0, stream);
+  dwm_fwd_kernel<<<g->N * a.tiles, 256, lds, (hipStream_t)stream>>>(a);
+  return cat::check_launch("dwm_fwd");
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------- per-step operand preparation
+namespace {
+
+__global__ __launch_bounds__(256) void prep_kernel(const cat_prep_job_t* __restrict__ jobs, int njobs, int accumulate) {
+  int ji = 0;
+  while (ji + 1 < njobs && (int)blockIdx.x >= jobs[ji].block0 + jobs[ji].nblocks) ++ji;
+  const cat_prep_job_t& J = jobs[ji];
+  const int64_t e = (int64_t)(blockIdx.x - J.block0) * 256 + threadIdx.x;
+  if (J.kind == 0) {   // tconv filter stream (see pack_kernel in conv_pk.hip): one float4 per thread
+    const int taps = J.ks * J.ks, nfull = J.c4 >> 4, rem = (J.c4 & 15) >> 2;
+    const int groups = nfull * taps + (rem ? (taps * rem + 3) / 4 : 0);
+    const int nt_own0 = J.col0 >> 4, nt_own1 = (J.col0 + J.Nn + 15) >> 4;   // N tiles this conv's columns touch
+    const int ntw = nt_own1 - nt_own0;
+    if (e >= (int64_t)groups * ntw * 64) return;
+    const int lane = (int)(e & 63);
+    const int64_t gj = e >> 6;
+    const int j = nt_own0 + (int)(gj % ntw);
+    const int G = (int)(gj / ntw);
+    int chunk, gi, nq;
+    if (G < nfull * taps) { chunk = G / taps; gi = G - chunk * taps; nq = 4; }
+    else { chunk = nfull; gi = G - nfull * taps; nq = rem; }
+    const int lr = lane & 15, lq = lane >> 4;
+    const int p = 4 * gi + lq;
+    const int tap = p / nq, qd = p - tap * nq;
+    const int col = j * 16 + lr, nn = col - J.col0;
+    if (nn < 0 || nn >= J.Nn) return;    // another conv's column (or padding, which stays 0 from the buffer's initialisation)
+    const float* w = J.srcs[0];
+    f4 v = {0.f, 0.f, 0.f, 0.f};
+    if (tap < taps) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int c = chunk * 16 + qd * 4 + t;
+        if (c < J.Ck) v[t] = J.mode == 0 ? w[(int64_t)nn * J.wn + tap * J.wcs + c] : w[(int64_t)c * J.wn + (taps - 1 - tap) * J.wcs + nn];
+      }
+    }
+    *reinterpret_cast<f4*>(J.dst + (((int64_t)G * J.nt_total + j) * 64 + lane) * 4) = v;
+  } else if (J.kind == 1) {
+    if (e >= J.n) return;
+    float s = 0.f;
+    for (int k = 0; k < J.nsrc; ++k) s += J.srcs[k][e];
+    J.dst[e] = s;
+  } else if (J.kind == 2) {   // depthwise filter into the 5 x 5 frame
+    const int taps = J.ks * J.ks;
+    if (e >= (int64_t)J.Nn * taps) return;
+    const int c = (int)(e / taps), tp = (int)(e - (int64_t)c * taps);
+    const int ky = tp / J.ks, kx = tp - ky * J.ks, o = 2 - (J.ks >> 1);
+    J.dst[((o + ky) * 5 + o + kx) * J.cs + J.col0 + c] = J.srcs[0][e];
+  } else {                    // scatter a slice of a concatenated gradient vector to its parameter
+    if (e >= J.n) return;
+    float* d = const_cast<float*>(J.srcs[1]);
+    const float v = J.srcs[0][e];
+    d[e] = accumulate ? d[e] + v : v;
+  }
+}
+
+}  // namespace
+
+extern "C" int cat_prep_run(const cat_prep_job_t* jobs_dev, int njobs, int total_blocks, int accumulate, cat_stream_t stream) {
+  CAT_REQUIRE(jobs_dev && njobs > 0 && total_blocks > 0, "prep: empty job table");
+  prep_kernel<<<total_blocks, 256, 0, (hipStream_t)stream>>>(jobs_dev, njobs, accumulate);
+  return cat::check_launch("prep_run");
+}

@@ -107,8 +107,9 @@ __global__ __launch_bounds__(256) void tconv_kernel(const cat_tconv_t g, const f
     s_act = g.seg[s].act;
     s_neg = s_act == CAT_ACT_RELU ? 0.f : (s_act == CAT_ACT_LRELU ? g.seg[s].slope : 1.f);
     if (s_aff) {
-      ssc = *reinterpret_cast<const f4*>(s_qv ? g.seg[s].scale + c0 + quad * 4 : g_zero);
-      ssh = *reinterpret_cast<const f4*>(s_qv ? g.seg[s].shift + c0 + quad * 4 : g_zero);
+      const int so = n * g.seg[s].sstride + c0 + quad * 4;
+      ssc = *reinterpret_cast<const f4*>(s_qv ? g.seg[s].scale + so : g_zero);
+      ssh = *reinterpret_cast<const f4*>(s_qv ? g.seg[s].shift + so : g_zero);
     }
   };
   auto sstore = [&](int buf, int s, int c0) {
@@ -257,6 +258,73 @@ __global__ __launch_bounds__(256) void tconv_kernel(const cat_tconv_t g, const f
     cpack = npack;
   }
 
+  if (g.stats) {
+    // per-tile sum and sum of squared deviations from the TILE mean of the pre-activation output (two passes over the accumulators:
+    // no E[x^2] - E[x]^2 cancellation); cat_tnorm_finalize merges the tiles with the exact pairwise formula
+    float* red = smem + 2 * tile_floats + 2 * TABN;   // [2][4 waves][NT * 16]
+    const int cnt = min(TH, g.Ho - oy0) * min(TW, g.Wo - ox0);
+    float s[NT], mean[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int co = (j0 + j) * 16 + lr;
+      const float b = (bias && co < g.Nn) ? bias[co] : 0.f;
+      float a = 0.f;
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const bool rowv = oy0 + 2 * wave + (MT == 2 ? i : (i >> 1)) < g.Ho;
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const bool v = rowv && ox0 + (MT == 2 ? 0 : (i & 1) * 16) + lq * 4 + rg < g.Wo;
+          a += v ? acc[i][j][rg] + b : 0.f;
+        }
+      }
+      a += __shfl_xor(a, 16, 64);
+      a += __shfl_xor(a, 32, 64);
+      s[j] = a;
+      if (lq == 0) red[wave * NT * 16 + j * 16 + lr] = a;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int c = j * 16 + lr;
+      s[j] = (red[c] + red[NT * 16 + c]) + (red[2 * NT * 16 + c] + red[3 * NT * 16 + c]);
+      mean[j] = s[j] / (float)cnt;
+    }
+    float* red2 = red + 4 * NT * 16;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int co = (j0 + j) * 16 + lr;
+      const float b = (bias && co < g.Nn) ? bias[co] : 0.f;
+      float a = 0.f;
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const bool rowv = oy0 + 2 * wave + (MT == 2 ? i : (i >> 1)) < g.Ho;
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const bool v = rowv && ox0 + (MT == 2 ? 0 : (i & 1) * 16) + lq * 4 + rg < g.Wo;
+          const float d = acc[i][j][rg] + b - mean[j];
+          a += v ? d * d : 0.f;
+        }
+      }
+      a += __shfl_xor(a, 16, 64);
+      a += __shfl_xor(a, 32, 64);
+      if (lq == 0) red2[wave * NT * 16 + j * 16 + lr] = a;
+    }
+    __syncthreads();
+    if (wave == 0 && lq == 0) {
+      float* dst = g.stats + (int64_t)tt * 2 * g.scs;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int c = j * 16 + lr, co = (j0 + j) * 16 + lr;
+        if (j0 + j < L.nt_total && co < g.ycw) {
+          const bool cv = co < g.Nn;
+          dst[co] = cv ? s[j] : 0.f;
+          dst[g.scs + co] = cv ? (red2[c] + red2[NT * 16 + c]) + (red2[2 * NT * 16 + c] + red2[3 * NT * 16 + c]) : 0.f;
+        }
+      }
+    }
+  }
+
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     const int oy = oy0 + 2 * wave + (MT == 2 ? i : (i >> 1));
@@ -354,15 +422,16 @@ int cat_tconv_fwd(const cat_tconv_t* g, const float* pack, const float* bias, fl
     const cat_tseg_t& sg = g->seg[s];
     CAT_REQUIRE(sg.ks == 1 || sg.ks == 3 || sg.ks == 5, "tconv: kernel size %d unsupported", sg.ks);
     CAT_REQUIRE(sg.c4 > 0 && (sg.c4 & 3) == 0 && (sg.xcs & 3) == 0 && sg.xcs >= sg.c4, "tconv: segment %d channel layout", s);
-    CAT_REQUIRE(sg.padv >= 0 && sg.padv < sg.ks, "tconv: segment %d padv", s);
+    CAT_REQUIRE(sg.padv >= 0 && sg.padv <= 4, "tconv: segment %d padv", s);
     CAT_REQUIRE(sg.act == CAT_ACT_NONE || sg.act == CAT_ACT_RELU || sg.act == CAT_ACT_LRELU, "tconv: staging activation %d", sg.act);
     CAT_REQUIRE(!sg.reflect || (sg.ks <= g->H && sg.ks <= g->W), "tconv: reflect padding wider than the plane");
     CAT_REQUIRE((int64_t)g->N * g->H * g->W * sg.xcs < (int64_t)4294967295LL, "tconv: source larger than 2^32 elements");
     hl = sg.padv > hl ? sg.padv : hl;
-    hr = sg.ks - 1 - sg.padv > hr ? sg.ks - 1 - sg.padv : hr;
+    hr = sg.ks - 1 - sg.padv > hr ? sg.ks - 1 - sg.padv : hr;   // stays >= 0: a segment whose taps all lie left of the origin needs none
     CAT_REQUIRE(sg.cin > 0 && sg.cin <= sg.c4, "tconv: segment %d valid channel count", s);
     kflops += (double)sg.ks * sg.ks * sg.cin;
   }
+  CAT_REQUIRE(hl + hr <= 4, "tconv: halo %d + %d exceeds the staged patch", hl, hr);
   static const int tw_env = getenv("CAT_PK_TW") ? atoi(getenv("CAT_PK_TW")) : 0;
   cat_pk::Launch L;
   L.nt_total = cat::cdiv(g->Nn, 16);
@@ -371,8 +440,9 @@ int cat_tconv_fwd(const cat_tconv_t* g, const float* pack, const float* bias, fl
   L.nblk = cat::cdiv(L.nt_total, nt);
   // 8 x 16 pixel tiles unless that makes a very large grid (then 8 x 32: half the halo traffic, twice the filter reuse per wave)
   const int64_t wg16 = (int64_t)g->N * cat::cdiv(g->Ho, 8) * cat::cdiv(g->Wo, 16) * L.nblk;
-  const int tw = tw_env ? tw_env : (wg16 >= 4096 ? 32 : 16);
+  const int tw = g->stats ? 16 : (tw_env ? tw_env : (wg16 >= 4096 ? 32 : 16));
   CAT_REQUIRE(tw == 16 || tw == 32, "tconv: CAT_PK_TW must be 16 or 32");
+  CAT_REQUIRE(g->stats == nullptr || (g->act == CAT_ACT_NONE && g->res == nullptr && g->scs >= g->ycw), "tconv: statistics need a plain epilogue");
   L.hl = hl;
   L.tr = cat_pk::TH + hl + hr;
   L.tc = tw + hl + hr;
@@ -380,9 +450,10 @@ int cat_tconv_fwd(const cat_tconv_t* g, const float* pack, const float* bias, fl
   L.tiles = L.tiles_x * cat::cdiv(g->Ho, cat_pk::TH);
   const int64_t grid = (int64_t)g->N * L.tiles * L.nblk;
   CAT_REQUIRE(grid < (int64_t)2147483647, "tconv: grid too large");
-  const size_t lds = (size_t)2 * L.tr * L.tc * cat_pk::PITCH * sizeof(float) + 2 * cat_pk::TABN * sizeof(int);
+  const size_t lds = (size_t)2 * L.tr * L.tc * cat_pk::PITCH * sizeof(float) + 2 * cat_pk::TABN * sizeof(int) +
+                     (g->stats ? (size_t)8 * nt * 16 * sizeof(float) : 0);
   hipStream_t s = (hipStream_t)stream;
-  cat::ProfScope prof(g->nseg > 1 ? "conv_tconv_multi" : "conv_tconv", 2.0 * (double)g->N * g->Ho * g->Wo * g->Nn * kflops, 0.0, stream);
+  cat::ProfScope prof(g->nseg > 1 ? "conv_tconv_multi" : "conv_tconv", 2.0 * (double)g->N * g->Ho * g->Wo * (g->nvalid > 0 ? g->nvalid : g->Nn) * kflops, 0.0, stream);
 #define CAT_PK_LAUNCH(NT, TW)                                                                                              \
   {                                                                                                                        \
     static bool attr_set = false;                                                                                          \

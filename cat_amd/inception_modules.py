@@ -9,6 +9,7 @@ import torch
 from torch import nn
 
 from . import frozen
+from . import fused_block
 from . import nn as cnn
 from . import ops
 
@@ -149,6 +150,8 @@ class InvertedResidualChannels(nn.Module):
             return x
         if frozen.applicable(self, x):      # eval + no_grad + BatchNorm: the frozen teacher's algebraically fused block
             return frozen.block_forward(self, x)
+        if fused_block.applicable(self, x):     # train-mode norms: 9 launches per block, norms folded into producers / consumers
+            return fused_block.apply(self, x)
         # one alias of x per consumer (branches + residual); their gradients are summed by one add_n kernel
         xs = ops.fanout(x, nb + 1)
         branch_ops = list(self.res_ops) + list(self.dw_ops)

@@ -147,6 +147,51 @@ def run_on_side_streams(fns, inputs):
     return outs
 
 
+class SideJobs:
+    """Independent kernel sequences of one backward node (weight-gradient launches of a fused block) dealt round-robin to the side
+    streams: `fork()` after their inputs are enqueued on the current stream, `run(fn)` per job, `join()` before the node returns (the
+    temporaries the jobs read are freed in current-stream order after that)."""
+
+    def __init__(self, device, width=6):
+        self.main = torch.cuda.current_stream()
+        self.on = _BRANCH_STREAMS
+        if self.on:
+            key = (device, self.main.cuda_stream)
+            pool = _SIDE.get(key)
+            if pool is None or len(pool) < width:
+                pool = [torch.cuda.Stream(device=device) for _ in range(max(width, 6))]
+                _SIDE[key] = pool
+            self.pool, self.used, self.k, self.width = pool, set(), 0, width
+
+    def fork(self):
+        self.ev = self.main.record_event() if self.on else None
+
+    def run(self, fn):
+        if not self.on:
+            return fn()
+        s = self.pool[self.k % self.width]
+        self.k += 1
+        if s not in self.used:
+            s.wait_event(self.ev)
+            self.used.add(s)
+        with torch.cuda.stream(s):
+            fn()
+
+    def refork(self):
+        """Later jobs depend on work enqueued on the main stream since fork()."""
+        if self.on:
+            self.ev = self.main.record_event()
+            for s in self.pool[:self.width]:
+                s.wait_event(self.ev)
+                self.used.add(s)
+
+    def join(self):
+        if self.on:
+            for s in self.used:
+                self.main.wait_event(s.record_event())
+            self.used = set()
+
+
 def to_nhwc(x):
     """NCHW-contiguous (reference layout) -> NHWC activation, through cat_nchw_to_nhwc."""
     _require_cuda(x)

@@ -254,6 +254,7 @@ typedef struct {
   const float* src;    /* [N][H][W][xcs], pointing at the segment's first channel (a channel slice of a wider buffer is fine) */
   const float* scale;  /* optional [c4] staging affine: v = act(src * scale + shift); NULL = none (act still applies) */
   const float* shift;
+  int sstride;         /* floats between per-image rows of scale / shift (InstanceNorm statistics); 0 = one row for the batch */
   int xcs, c4;         /* pixel stride of src, channels of this segment (multiple of 4; padding channels must read as 0 after f_s) */
   int cin;             /* valid channels (<= c4): FLOP accounting only */
   int ks, padv;        /* ks x ks taps; output pixel (oy, ox) reads src pixel (oy - padv + ky, ox - padv + kx) */
@@ -264,10 +265,16 @@ typedef struct {
 } cat_tseg_t;
 typedef struct {
   const float* res;    /* optional residual added AFTER the epilogue activation: y = act(acc + bias) + res (the block's skip connection) */
+  float* stats;        /* optional per-tile statistics of the PRE-activation output for a following train-mode norm layer:
+                          stats[(tile*2 + 0)*scs + co] = sum over the tile's valid pixels, [(tile*2 + 1)*scs + co] = sum of squared
+                          deviations from the tile mean (combined exactly by cat_tnorm_finalize); tile = image * tiles_per_image + t,
+                          8 x 16 pixel tiles in row-major order.  Forces the 8 x 16 tiling. */
   int rcs;             /* pixel stride of res */
+  int scs;             /* floats per statistics row (>= the columns this launch owns; `stats` points at its first column) */
   int N, H, W;         /* source planes (all segments) */
   int Ho, Wo;          /* output plane */
   int Nn, ycs, ycw;    /* output channels, pixel stride, channels [Nn, ycw) are written as 0 */
+  int nvalid;          /* output channels that are real (N-concatenated launches carry zero-filter padding columns): FLOP accounting only; 0 = Nn */
   int act;             /* epilogue activation */
   float slope;
   int nseg;
@@ -279,6 +286,63 @@ size_t cat_tconv_pack_floats(int ks, int c4, int Nn);
  * mode 1 (dgrad):    W(tap, c, n) = w[c*wn + (ks*ks-1-tap)*wcs + n], w = [Ck][ks*ks][wcs] conv weight (Ck = its Cout, Nn = its Cin) */
 int cat_tconv_pack(const float* w, int mode, int Nn, int Ck, int ks, int wcs, int wn, int c4, float* dst, cat_stream_t stream);
 int cat_tconv_fwd(const cat_tconv_t* g, const float* pack, const float* bias, float* y, cat_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Train-mode norm layers of an InvertedResidualChannels block without their own passes (csrc/block_norm.hip): the producing
+ * conv leaves per-tile statistics (cat_tconv_fwd `stats`, cat_dwm_fwd), cat_tnorm_finalize turns the table of ALL branches of a
+ * block stage into scale / shift (+ running statistics of every branch's nn.BatchNorm2d, inception_modules.py:43-44,150-173), and
+ * the consumer applies them while staging its input.  gamma / beta: the stage's affine parameters concatenated in the table's
+ * channel order (cat_prep_run gathers them), NULL = no affine.  scale / shift / mean / rstd: [G][scs]; G = 1 (BatchNorm) or N
+ * (InstanceNorm).  Biased variance, eps inside the sqrt, running_var gets the unbiased one (torch semantics). */
+#define CAT_TNORM_MAXSLICE 8
+typedef struct {
+  int c0, c;                 /* channels [c0, c0 + c) of the table belong to this norm module */
+  float* running_mean;       /* [c] or NULL */
+  float* running_var;
+  int64_t* num_batches;      /* nn.BatchNorm2d.num_batches_tracked or NULL */
+} cat_nslice_t;
+int cat_tnorm_finalize(const float* part, int scs, int G, int N, int Ho, int Wo, const float* gamma, const float* beta, int nslices,
+                       const cat_nslice_t* slices, float eps, float momentum, float* scale, float* shift, float* mean, float* rstd,
+                       int mstride, cat_stream_t stream);   /* mean / rstd rows are mstride floats apart (scs, or C for cat_norm_bwd) */
+/* cat_reflect_pad_bwd on channel slices: dxp / dx / add have their own pixel strides, C4 channels (multiple of 4) are folded and
+ * `add` (optional) is added -- the skip connection's gradient joins the folded first-conv input gradient in the same pass. */
+int cat_reflect_pad_bwd2(const float* dxp, int pcs, float* dx, int dcs, const float* add, int acs, int N, int H, int W, int C4, int pad,
+                         cat_stream_t stream);
+/* y = act(x * scale[g][c] + shift[g][c]) (+ res): the stand-alone apply of such a norm -- the block output
+ * x + pw_bn(sum) (inception_modules.py:235-236) and the re-materialisation of a hidden activation in the backward pass.
+ * x / y / res: [G][Pg][*cs], C4 channels (multiple of 4) are processed; sstride = floats between the groups' scale rows. */
+int cat_affine_res_fwd(const float* x, int xcs, const float* scale, const float* shift, int sstride, const float* res, int rcs, float* y,
+                       int ycs, int G, int Pg, int C4, int act, float slope, cat_stream_t stream);
+/* All depthwise convs of a block (the groups=midp ConvBNReLU convs, inception_modules.py:166-173; k = 1 / 3 / 5 per channel quad) as one
+ * launch over channel slices: input = first-stage pre-norm buffer with that stage's scale / shift + activation applied while staging,
+ * output = concatenated pre-norm buffer + its per-tile statistics.  w25: [25][4*nq] filters embedded in a 5 x 5 frame (cat_prep_run). */
+#define CAT_DWM_MAXQ 16
+typedef struct {
+  int N, H, W;
+  int nq;               /* channel quads */
+  int xcs, ycs, scs;    /* pixel strides of x / y, floats per statistics row */
+  int sstride;          /* floats between per-image scale rows (InstanceNorm), 0 = one group */
+  int reflect, act;
+  float slope;
+  int ks[CAT_DWM_MAXQ];
+} cat_dwm_t;
+int cat_dwm_fwd(const cat_dwm_t* g, const float* x, const float* scale, const float* shift, const float* w25, const float* bias, float* y,
+                float* stats, cat_stream_t stream);
+/* Per-step preparation of a block's operands in ONE launch, driven by a job table resident in HBM (built once per network):
+ *   kind 0  pack a conv weight for cat_tconv_fwd into columns [col0, col0 + Nn) of a stream with nt_total 16-wide N tiles (N-concatenated
+ *           first convs; mode as cat_tconv_pack)
+ *   kind 1  dst[i] = sum_k srcs[k][i], i < n     (concatenated gamma / beta / bias vectors; the summed bias of the branch sum)
+ *   kind 2  depthwise filter [C][ks][ks] -> dst[tap25][cs] 5 x 5 frame, channels [col0, col0 + C)
+ *   kind 3  dsts[k][i] (+)= src[i], i < n         (scatter a concatenated parameter gradient back; accumulate = cat_prep_run's flag) */
+#define CAT_PREP_MAXSRC 8
+typedef struct {
+  const float* srcs[CAT_PREP_MAXSRC];
+  float* dst;
+  int kind, nsrc, n;
+  int mode, Nn, Ck, ks, wcs, wn, c4, nt_total, col0, cs;
+  int block0, nblocks;   /* this job owns blocks [block0, block0 + nblocks) of 256 threads */
+} cat_prep_job_t;
+int cat_prep_run(const cat_prep_job_t* jobs_dev, int njobs, int total_blocks, int accumulate, cat_stream_t stream);
 
 #ifdef __cplusplus
 }
