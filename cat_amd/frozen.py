@@ -118,14 +118,7 @@ def _plan(block):
             b_f += last.bias.detach() * s_pw
         wides.append(dict(op=op, w2=w2, k=last.kernel_size[0]))
     act, slope = cnn._act_code(act_mod)
-    # packed filters of the fused tail: segment 0 = F (1x1 over the concatenated hidden buffer), then one segment per wide branch
-    from . import tconv
-    packs = [tconv.pack(w_f, tconv.FWD)] + [tconv.pack(wd['w2'], tconv.FWD) for wd in wides]
-    pack_offs, po = [], 0
-    for pk in packs:
-        pack_offs.append(po)
-        po += pk.numel()
-    plan = dict(key=key, tail_pack=torch.cat(packs), tail_offs=pack_offs, hc=hc, w_a=w_a, b_a=b_a.contiguous(), w_f=w_f, b_f=b_f.contiguous(), dws=dws, wides=wides, act=act, slope=slope,
+    plan = dict(key=key, tail_pack=None, tail_offs=None, hc=hc, w_a=w_a, b_a=b_a.contiguous(), w_f=w_f, b_f=b_f.contiguous(), dws=dws, wides=wides, act=act, slope=slope,
                 pad_mode=pad_mode, copies=[(o, sz) for (kind, _), (o, m, sz) in zip(slots, offs) if kind == 'res'])
     block._cat_frozen = plan
     return plan
@@ -172,6 +165,13 @@ def block_forward(block, x):
     if not fused_tail:
         return ops.AddNFn.apply(x, *outs)
     from . import tconv
+    if p['tail_pack'] is None:      # packed filters of the fused tail (once per plan): segment 0 = F, then one segment per wide branch
+        packs = [tconv.pack(p['w_f'], tconv.FWD)] + [tconv.pack(wd['w2'], tconv.FWD) for wd in p['wides']]
+        offs, po = [], 0
+        for pk in packs:
+            offs.append(po)
+            po += pk.numel()
+        p['tail_pack'], p['tail_offs'] = torch.cat(packs), offs
     refl = p['pad_mode'] == L.PAD_REFLECT
     segs = [tconv.Segment(outs[0], 1, 0, False, p['tail_offs'][0])]
     for wd, hid, off in zip(p['wides'], outs[1:], p['tail_offs'][1:]):
