@@ -236,10 +236,16 @@ class BaseInceptionDistiller:
             errors_set[key] = float(getattr(self, 'loss_' + name))
         return errors_set
 
+    def finish_pending(self):
+        """Complete work a schedule deferred past optimize_parameters (the data-parallel step keeps the student's gradient all-reduce
+        and Adam update in flight until the weights are needed): called by everything that reads weights or optimizer state."""
+
     def get_current_visuals(self):
+        self.finish_pending()
         return OrderedDict((n, getattr(self, n)) for n in self.visual_names if hasattr(self, n))
 
     def update_learning_rate(self, logger=None):
+        self.finish_pending()       # a pending Adam step must use the learning rate of the step that produced its gradient
         for scheduler in self.schedulers:
             scheduler.step()
         lr = self.optimizers[0].param_groups[0]['lr']
@@ -262,6 +268,9 @@ class BaseInceptionDistiller:
         opt = self.opt
         if getattr(opt, 'restore_teacher_G_path', None):
             self._load(self.netG_teacher, opt.restore_teacher_G_path, verbose)
+        else:       # the reference loads it unconditionally (base_inception_distiller.py:343): distilling from a random teacher is never intended
+            import warnings
+            warnings.warn('restore_teacher_G_path is not set: the teacher keeps its initialisation (synthetic-weight runs only)')
         if getattr(opt, 'restore_student_G_path', None):
             self._load(self.netG_student, opt.restore_student_G_path, verbose)
         if getattr(opt, 'restore_D_path', None):
@@ -276,6 +285,7 @@ class BaseInceptionDistiller:
                     param_group['lr'] = opt.lr
 
     def save_networks(self, epoch):
+        self.finish_pending()
         os.makedirs(self.save_dir, exist_ok=True)
 
         def cpu_sd(net):   # NCHW/OIHW-contiguous values, the checkpoint wire format
@@ -293,6 +303,7 @@ class BaseInceptionDistiller:
         dumps, `is_best` / running-mean bookkeeping; the FID / mIoU networks themselves are the integrator's callables
         `self.fid_fn(fakes)`, `self.miou_fn(fakes, names)` (cat_amd/distillers/evaluation.py, INTEGRATION.md)."""
         from . import evaluation as E
+        self.finish_pending()
         aligned = self.opt.dataset_mode == 'aligned'
 
         def images(j):
@@ -305,5 +316,6 @@ class BaseInceptionDistiller:
                           save_all=save_image)
 
     def test(self, teacher_forward=True):
+        self.finish_pending()
         with torch.no_grad():
             self.forward(teacher_forward=teacher_forward)

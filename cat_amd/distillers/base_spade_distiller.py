@@ -175,6 +175,9 @@ class BaseSPADEDistiller:
             errors_set[key] = float(getattr(self, 'loss_' + name))
         return errors_set
 
+    def finish_pending(self):
+        """No deferred work in the SPADE step (gradient buckets are reduced synchronously); kept for the Trainer-facing surface."""
+
     def get_current_visuals(self):
         return OrderedDict((n, getattr(self, n)) for n in self.visual_names if hasattr(self, n))
 

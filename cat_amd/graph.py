@@ -19,7 +19,10 @@ class GraphedStep:
         if getattr(model, 'dp', None) is not None:
             raise RuntimeError('GraphedStep: data-parallel steps are not captured (collectives between the backward passes)')
         self.model = model
-        self.static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in example_batch.items()}
+        # static input buffers live on the model's device (a DataLoader batch is a host tensor: its H2D copy is done per call,
+        # outside the graph); non-tensor entries (image paths) are refreshed per call
+        dev = getattr(model, 'device', None) or torch.device('cuda', torch.cuda.current_device())
+        self.static = {k: (v.to(dev).clone() if torch.is_tensor(v) else v) for k, v in example_batch.items()}
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream()
         side.wait_stream(cur)
@@ -37,9 +40,26 @@ class GraphedStep:
 
     def __call__(self, batch):
         for k, v in batch.items():
+            if torch.is_tensor(v) and (k not in self.static or tuple(v.shape) != tuple(self.static[k].shape)):
+                # e.g. the smaller last batch of an epoch: shapes are baked into the capture -> run this step eagerly
+                self.model.set_input(batch)
+                self.model.optimize_parameters(self.replays)
+                return
+        for k, v in batch.items():
             if torch.is_tensor(v):
                 self.static[k].copy_(v, non_blocking=True)
+            else:
+                self.static[k] = v
+        for opt in self.model.optimizers:       # LambdaLR / manual lr changes since the capture
+            if hasattr(opt, 'sync_hyper_for_replay'):
+                opt.sync_hyper_for_replay()
         self.graph.replay()
+        # host-side field set_input would have refreshed (base_inception_distiller.py set_input: A_paths / B_paths / path)
+        opt_ = getattr(self.model, 'opt', None)
+        key = 'A_paths' if getattr(opt_, 'direction', 'AtoB') == 'AtoB' else 'B_paths'
+        paths = batch.get('path', batch.get(key))
+        if paths is not None:
+            self.model.image_paths = paths
         for opt in self.model.optimizers:
             opt.note_graph_replay()
         self.replays += 1

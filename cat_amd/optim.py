@@ -131,6 +131,18 @@ class FusedAdam(torch.optim.Optimizer):
             L.call('cat_adam_step_dev', C.c_void_p(f['p'].data_ptr()), C.c_void_p(f['g'].data_ptr()), C.c_void_p(f['m'].data_ptr()),
                    C.c_void_p(f['v'].data_ptr()), f['n'], C.c_void_p(f['hyper'].data_ptr()), float(self.grad_scale), stream)
 
+    def sync_hyper_for_replay(self):
+        """Before replaying a captured step: if a scheduler (LambdaLR linear decay) or the user changed lr / betas / eps / weight_decay
+        since the capture, rewrite those device-resident scalars (the step counter and the bias corrections stay with the device)."""
+        for group, f in zip(self.param_groups, self._ensure_flat()):
+            if f is None or f['hyper_host'] is None:
+                continue
+            b1, b2 = group['betas']
+            host5 = (float(group['lr']), float(b1), float(b2), float(group['eps']), float(group['weight_decay']))
+            if f['hyper_host'][:5] != host5:
+                f['hyper'][:5].copy_(torch.tensor(host5, dtype=torch.float32))
+                f['hyper_host'] = host5 + f['hyper_host'][5:]
+
     def note_graph_replay(self):
         """A captured step was replayed: the device-side step counter advanced, keep the host mirror in sync."""
         _bump_weights_epoch()

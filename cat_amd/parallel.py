@@ -97,6 +97,13 @@ class DataParallelReducer:
                     stage = d.contiguous()
                     dist.broadcast(stage, src=src, group=self.group)
                     d.copy_(stage)
+                t.__dict__.pop('_cat_pk', None)        # packed-filter cache of the LDS-tile convs
+            # the broadcast wrote through .data (no version bump): drop every cache derived from the old values
+            for sub in m.modules():
+                for attr in ('_cat_frozen', '_cat_fold', '_cat_fused_plan'):
+                    sub.__dict__.pop(attr, None)
+        from . import optim
+        optim._bump_weights_epoch()
 
     def all_reduce_sum_(self, t):
         """In-place sum over ranks, ordered with the CURRENT stream (SynchronizedBatchNorm's [sum x | sum x^2] exchange,

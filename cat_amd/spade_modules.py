@@ -230,6 +230,9 @@ class SPADEDistillerModules(nn.Module):
             raise NotImplementedError('load_pretrained_weight (utils/weight_transfer.py) is outside the accelerated hot path')
         if getattr(opt, 'restore_teacher_G_path', None):
             load(self.netG_teacher, opt.restore_teacher_G_path)
+        else:       # the reference loads it unconditionally (spade_model_modules.py): a random teacher is never intended
+            import warnings
+            warnings.warn('restore_teacher_G_path is not set: the teacher keeps its initialisation (synthetic-weight runs only)')
         if teacher_only:
             return
         if getattr(opt, 'restore_student_G_path', None) is not None:
