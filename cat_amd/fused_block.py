@@ -234,6 +234,7 @@ class _Plan:
         if b2:
             fwd.append(vec(self.bias2, 0, b2, self.C))
         self.ptrs = tuple(p.data_ptr() for p in self.block.parameters())
+        self.shapes = tuple(tuple(p.shape) for p in self.block.parameters())
         self.fwd_jobs = self._jobs_to_dev(fwd)
         self.bwd_jobs = self._jobs_to_dev(bwd)
 
@@ -243,6 +244,11 @@ class _Plan:
 
     def prepare(self, backward=False):
         """Refresh the derived operands if a weight changed since the last refresh (once per optimizer step)."""
+        if tuple(q.data_ptr() for q in self.block.parameters()) != self.ptrs:
+            # parameter storage moved since the tables were built (FusedAdam flattens its parameters at its first zero_grad / step,
+            # i.e. between the first forward and the first backward): same layout, new source addresses
+            self._build_jobs()
+            self.key = self.bkey = self.scatter_jobs = None
         key = self._epoch_key()
         if backward:
             if self.bkey != key:
@@ -257,8 +263,7 @@ class _Plan:
 
 def plan_for(block, x):
     p = getattr(block, '_cat_fused_plan', None)
-    ptrs = tuple(q.data_ptr() for q in block.parameters())
-    if p is None or p.ptrs != ptrs or p.dev != x.device:
+    if p is None or p.dev != x.device or p.shapes != tuple(tuple(q.shape) for q in block.parameters()):
         p = _Plan(block, x.device)
         block._cat_fused_plan = p
     return p
@@ -395,6 +400,8 @@ class _BlockFn(torch.autograd.Function):
         pad_mode = L.PAD_REFLECT if p.reflect else L.PAD_ZERO
 
         side = ops.SideJobs(dev)
+        keep = []      # temporaries read by side-stream launches stay referenced until side.join(): freed earlier, the caching allocator
+        #                would hand their memory to the next main-stream kernel while a side stream still reads it
 
         def put(param, kernel):
             grads[id(param)] = ops._write_param_grad(param, kernel)
@@ -483,6 +490,7 @@ class _BlockFn(torch.autograd.Function):
                 L.call('cat_slice_channels', ops._p(a1), p.hc1, b['o1'], w1, ops._p(xa), w1, m_pix, st)
                 L.call('cat_slice_channels', ops._p(dzd), p.hcd, b['od'], w1, ops._p(dyc), w1, m_pix, st)
                 gww = ops._conv_geom(n, h, w, m, w1, h, w, m, w1, kd, kd, 1, pd, moded)
+                keep += [xa, dyc]
 
                 def kdw(dst_, acc, sst, gww=gww, xa=xa, dyc=dyc):
                     ws = ops.workspace(L.query('cat_dwconv2d_wgrad_ws_bytes', C.byref(gww)), dev)
@@ -524,6 +532,7 @@ class _BlockFn(torch.autograd.Function):
             else:
                 tconv.run(segs, p.dpack1, None, dx, c, n, h, w, h, w, res=dy)
         side.join()
+        del keep
         # ---- 9. scatter the concatenated parameter gradients
         owned = [getattr(q, '_cat_grad_view', None) is not None for _, _, _, q in p.targets]
         if p.targets and all(owned):

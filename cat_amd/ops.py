@@ -302,6 +302,15 @@ def _nchw(t):
 
 # ---------------------------------------------------------------------------------------------- convolutions
 _TCONV = os.environ.get('CAT_TCONV', '1') != '0'      # LDS-tile kernels with packed filters for stride-1 3x3 / 5x5 layers (A/B switch)
+_TCONV_MIN_TILES = int(os.environ.get('CAT_TCONV_MIN_TILES', '96'))
+
+
+def set_tconv_min_tiles(n):
+    """Fewest 8 x 16 output tiles for which the LDS-tile kernels (and the fused block path built on them) are chosen.  The default keeps
+    planes that cannot fill the chip on the split-K im2col kernels; tests lower it to drive small batches through the same kernels."""
+    global _TCONV_MIN_TILES
+    old, _TCONV_MIN_TILES = _TCONV_MIN_TILES, int(n)
+    return old
 
 
 def tconv_applicable(n, h, w, cout, kh, kw, stride, pad):
@@ -309,7 +318,7 @@ def tconv_applicable(n, h, w, cout, kh, kw, stride, pad):
     input gradient); tiny planes (the SPADE generators' 4x8 .. 16x32 stages) keep the split-K im2col kernels, Cout <= 3 the direct ones."""
     if not _TCONV or stride != 1 or kh != kw or kh not in (3, 5) or pad != (kh - 1) // 2 or cout <= 3:
         return False
-    return n * ((h + 7) // 8) * ((w + 15) // 16) >= 96
+    return n * ((h + 7) // 8) * ((w + 15) // 16) >= _TCONV_MIN_TILES
 
 
 def packed_filter(weight, wcl, mode):

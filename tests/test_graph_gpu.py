@@ -50,6 +50,21 @@ def test_graph_replay_equals_eager_inception():
     assert _max_param_diff(graphed.netD, eager.netD) < 1e-5
     assert graphed.optimizer_G._flat[0]['step'] == eager.optimizer_G._flat[0]['step'] == 6
     assert float(graphed.optimizer_G._flat[0]['hyper'][5]) == 6.0
+    # a learning-rate schedule (LambdaLR's linear decay, or update_learning_rate) between replays reaches the device-resident scalars
+    for m in (eager, graphed):
+        for o in m.optimizers:
+            for grp in o.param_groups:
+                grp['lr'] = grp['lr'] * 0.37
+    eager.set_input(batches[2])
+    eager.optimize_parameters(7)
+    step(batches[2])
+    assert abs(float(graphed.optimizer_G._flat[0]['hyper'][0]) - eager.optimizer_G.param_groups[0]['lr']) < 1e-9
+    assert _max_param_diff(graphed.netG_student, eager.netG_student) < 1e-5
+    assert _max_param_diff(graphed.netD, eager.netD) < 1e-5
+    # a batch of another shape (the last batch of an epoch) falls back to eager launches instead of failing in copy_
+    small = {k: (v[:1] if torch.is_tensor(v) else v) for k, v in batches[1].items()}
+    step(small)
+    assert graphed.Sfake_B.shape[0] == 1
 
 
 def test_graph_replay_equals_eager_spade():

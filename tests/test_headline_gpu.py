@@ -1,0 +1,167 @@
+"""GPU parity at the HEADLINE size (BASELINE configs[1]: 256 x 256, the bench's pruned student, ndf 128 PatchGAN, hinge + L1 + KA):
+the step fixtures under tests/golden are 64 x 64, where the student's trunk is 16 x 16 pixels and the LDS-tile / fused-block kernels
+the bench runs are never selected.  Here one optimize_parameters at 256 x 256 runs through exactly those kernels and is compared with
+the CPU oracle on the same weights and images (batch 2: ~10 s of host work); observed maxima are printed for DESIGN.md §5."""
+import argparse
+import json
+
+import numpy as np
+import pytest
+import torch
+
+import helpers as H
+from oracle import detfill, ref_cpu
+
+pytestmark = pytest.mark.gpu
+
+
+def _cpu(net):
+    return {k: v.detach().cpu().contiguous().clone() for k, v in net.state_dict().items()}
+
+
+@pytest.fixture(scope='module')
+def c2():
+    import bench
+    from cat_amd import _lib, ops
+    _lib.load()
+    old = ops.set_tconv_min_tiles(1)          # batch 2 @ 64 x 64 trunk = 64 tiles: take the kernels the batch-16 bench takes
+    args = argparse.Namespace(workload='c2', batch=2, size=256, target_flops=4.6e9)
+    model, opt = bench.build_model(args, 0)
+    yield model, opt
+    ops.set_tconv_min_tiles(old)
+
+
+def test_c2_step_at_256_matches_oracle(c2, capsys):
+    from cat_amd import ops
+    model, opt = c2
+    ncfg = {'norm': 'batch', 'eps': opt.norm_epsilon, 'momentum': opt.norm_momentum}
+    cfg = dict(T=ncfg, S=ncfg, D=ncfg, dataset_mode='aligned', gan_mode='hinge', lambda_recon=100.0, lambda_distill=1.3, lambda_gan=1.0, lr=opt.lr,
+               beta1=opt.beta1)
+    st = ref_cpu.DistillState(_cpu(model.netG_teacher), _cpu(model.netG_student), _cpu(model.netD), cfg)
+    A, B = detfill.images((2, 3, 256, 256), 71), detfill.images((2, 3, 256, 256), 72)
+    ref = ref_cpu.distill_step(st, A, B)
+    model.set_input({'A': A, 'B': B, 'A_paths': [], 'B_paths': []})
+    ops.STATS['conform_copies'] = 0
+    # optimize_parameters (inception_distiller.py:179-188) spelled out, so that the student's gradients can be read before Adam
+    # consumes them
+    model.forward()
+    model.set_requires_grad(model.netD, True)
+    model.optimizer_D.zero_grad()
+    model.backward_D()
+    model.optimizer_D.step()
+    model.set_requires_grad(model.netD, False)
+    model.optimizer_G.zero_grad()
+    model.backward_G(0)
+    torch.cuda.synchronize()
+    import test_spade_gpu as TS
+    with capsys.disabled():
+        TS.check_grads(model.netG_student.named_parameters(), st.grads_S)      # prints worst / median / share of tensors within 1e-3
+    model.optimizer_G.step()
+    torch.cuda.synchronize()
+    got = model.get_current_losses()
+    report = {}
+    for k, v in ref.items():
+        pref = 'Specific_loss/' if k[-1].isdigit() else ('D_loss/' if k.startswith('D_') else 'G_loss/')
+        report[k] = abs(got[pref + k] - v) / max(1.0, abs(v))
+    report['Sfake_B'] = H.rel_err(model.Sfake_B.detach().cpu().numpy(), st.Sfake_B.numpy())
+    report['Tfake_B'] = H.rel_err(model.Tfake_B.detach().cpu().numpy(), st.Tfake_B.numpy())
+    # updated weights: Adam's first step is -lr * sign(grad), so an element whose gradient is within round-off of zero may land 2 * lr
+    # away; the bulk (75 % quantile of every tensor) agrees to round-off and nothing moves further than a flipped step
+    worst_q, worst_k = 0.0, None
+    for name, sd, ref_sd in (('S', model.netG_student.state_dict(), st.S), ('D', model.netD.state_dict(), st.D)):
+        for k, v in sd.items():
+            if not v.dtype.is_floating_point:
+                continue
+            d = (v.detach().cpu() - ref_sd[k]).abs().reshape(-1).numpy()
+            scale = float(ref_sd[k].abs().max()) + 1e-12
+            q = float(np.quantile(d, 0.75)) / max(scale, 10 * opt.lr)
+            if q > worst_q:
+                worst_q, worst_k = q, (name, k, float(d.max()), scale)
+            assert d.max() <= 2.5 * opt.lr + 2e-3 * scale, (name, k, d.max(), scale)
+    report['weights_q75'] = worst_q
+    with capsys.disabled():
+        print('\n[headline parity @256x256, batch 2] max relative deviation from the CPU oracle: ' + json.dumps({k: float('%.3g' % v) for k, v in report.items()}))
+    assert ops.STATS['conform_copies'] == 0
+    for k, v in report.items():
+        assert v < 1e-3, (k, v)
+
+
+def test_eval_forward_is_batch_independent_at_16(c2):
+    """Size-independent property at the bench's batch: in eval mode (running statistics) the student's output for sample i of a batch
+    of 16 equals the oracle's output for that sample alone."""
+    from cat_amd import ops, synthetic
+    model, opt = c2
+    ncfg = {'norm': 'batch', 'eps': opt.norm_epsilon, 'momentum': opt.norm_momentum}
+    x = synthetic.images((16, 3, 256, 256), 81)
+    S = model.netG_student
+    S.eval()
+    try:
+        with torch.no_grad():
+            y = S(ops.to_nhwc(x.cuda()))
+    finally:
+        S.train()
+    assert torch.isfinite(y).all()
+    ref, _ = ref_cpu.inception_generator(_cpu(S), x[5:7], ncfg, training=False)
+    assert H.rel_err(y[5:7].detach().cpu().numpy(), ref.numpy()) < 1e-3
+
+
+def test_checkpoint_round_trip_and_oracle_interchange(c2, tmp_path):
+    """save_networks writes reference-format state_dicts (NCHW / OIHW values under the reference's keys); the oracle loads
+    them and reproduces the GPU student's forward, and a state_dict produced on the oracle side loads into the cat_amd student."""
+    import os
+    from cat_amd import ops
+    model, opt = c2
+    model.save_dir = str(tmp_path)
+    model.save_networks('latest')
+    sd = torch.load(os.path.join(str(tmp_path), 'latest_net_G.pth'), map_location='cpu')
+    assert list(sd.keys()) == list(model.netG_student.state_dict().keys())
+    assert all(v.is_contiguous() for v in sd.values())
+    assert os.path.exists(os.path.join(str(tmp_path), 'latest_net_D.pth')) and os.path.exists(os.path.join(str(tmp_path), 'latest_optim-0.pth'))
+    ncfg = {'norm': 'batch', 'eps': opt.norm_epsilon, 'momentum': opt.norm_momentum}
+    x = detfill.images((2, 3, 256, 256), 91)
+    S = model.netG_student
+    S.eval()
+    try:
+        with torch.no_grad():
+            y = S(ops.to_nhwc(x.cuda())).detach().cpu().numpy()
+        ref, _ = ref_cpu.inception_generator(sd, x, ncfg, training=False)
+        assert H.rel_err(y, ref.numpy()) < 1e-3
+        # reverse direction: an oracle-side state_dict (fresh values under the same keys / logical shapes) into the GPU student
+        new_sd = detfill.fill_state_dict({k: v.clone() for k, v in sd.items()}, 1234, gamma_abs_normal=True)
+        S.load_state_dict(new_sd)
+        with torch.no_grad():
+            y2 = S(ops.to_nhwc(x.cuda())).detach().cpu().numpy()
+        ref2, _ = ref_cpu.inception_generator(new_sd, x, ncfg, training=False)
+        assert H.rel_err(y2, ref2.numpy()) < 1e-3
+        # optimizer state survives a save / load cycle
+        osd = torch.load(os.path.join(str(tmp_path), 'latest_optim-0.pth'), map_location='cpu')
+        model.optimizer_G.load_state_dict(osd)
+    finally:
+        S.load_state_dict(sd)
+        S.train()
+
+
+def test_evaluate_model_on_gpu(c2, tmp_path):
+    """evaluate_model over a synthetic dataloader -- student inference on the kernels (eval-mode norms), image dumps,
+    the reference's FID bookkeeping with a stub metric callable -- and the fakes equal the oracle's eval-mode forward."""
+    import os
+    from cat_amd import synthetic
+    model, opt = c2
+    opt.log_dir = str(tmp_path)
+    ncfg = {'norm': 'batch', 'eps': opt.norm_epsilon, 'momentum': opt.norm_momentum}
+    batches = [{'A': synthetic.images((2, 3, 256, 256), 300 + i), 'B': synthetic.images((2, 3, 256, 256), 400 + i),
+                'A_paths': [f'/d/{i}_a.jpg', f'/d/{i}_b.jpg'], 'B_paths': [f'/d/{i}_a.jpg', f'/d/{i}_b.jpg']} for i in range(2)]
+    model.eval_dataloader = batches
+    seen = {}
+
+    def fid(fakes):
+        seen['fakes'] = fakes
+        return 12.5
+    model.fid_fn = fid
+    model.best_fid, model.fids, model.best_mIoU, model.mIoUs = 1e9, [], -1e9, []
+    out = model.evaluate_model(7)
+    assert out['metric/fid'] == 12.5 and model.is_best and model.netG_student.training
+    assert len(seen['fakes']) == 2 and tuple(seen['fakes'][0].shape) == (2, 3, 256, 256)
+    ref, _ = ref_cpu.inception_generator(_cpu(model.netG_student), batches[1]['A'], ncfg, training=False)
+    assert H.rel_err(seen['fakes'][1].numpy(), ref.numpy()) < 1e-3
+    assert os.path.exists(os.path.join(str(tmp_path), 'eval', '7', 'Sfake', '1_b.png'))
