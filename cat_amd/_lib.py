@@ -44,6 +44,10 @@ class NSlice(C.Structure):
     _fields_ = [('c0', c_i), ('c', c_i), ('running_mean', c_p), ('running_var', c_p), ('num_batches', c_p)]
 
 
+class Stage1Geom(C.Structure):
+    _fields_ = [(n, c_i) for n in ('N', 'H', 'W', 'xcs', 'cin', 'reflect', 'ycs', 'scs')] + [('col0', c_i * 3), ('width', c_i * 3), ('nvalid', c_i * 3)]
+
+
 class DwmGeom(C.Structure):
     _fields_ = [(n, c_i) for n in ('N', 'H', 'W', 'nq', 'xcs', 'ycs', 'scs', 'sstride', 'reflect', 'act')] + [('slope', c_f), ('ks', c_i * DWM_MAXQ)]
 
@@ -74,6 +78,8 @@ SIGNATURES = {
     'cat_tconv_pack_floats': (C.c_size_t, [c_i, c_i, c_i]),
     'cat_tconv_pack': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
     'cat_tconv_fwd': (c_i, [_TG, c_p, c_p, c_p, c_p]),
+    'cat_tstage1_supported': (c_i, [c_i, c_i, c_i]),
+    'cat_tstage1_fwd': (c_i, [C.POINTER(Stage1Geom), c_p, c_p, c_p, c_p, c_p, c_p]),
     'cat_tnorm_finalize': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_i, c_p]),
     'cat_reflect_pad_bwd2': (c_i, [c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     'cat_affine_res_fwd': (c_i, [c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_p]),

@@ -45,16 +45,39 @@ __global__ __launch_bounds__(256) void tnorm_finalize_kernel(const float* __rest
   }
   const int per_img = tiles, ntile = tiles * imgs_per_group;
   const float* pg = part + (int64_t)g * ntile * 2 * scs + c;
+  // every lane fetches its tiles' (sum, M2) pairs up front (independent loads: one L2 round trip instead of one per tile and pass)
+  constexpr int R = 16;                  // tiles per lane kept in registers (1024 tiles); longer tables loop
   float s = 0.f;
-  for (int t = lane; t < ntile; t += 64) s += pg[(int64_t)t * 2 * scs];
+  float sv[R], mv[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int t = lane + 64 * r;
+    const bool v = t < ntile;
+    sv[r] = v ? pg[(int64_t)t * 2 * scs] : 0.f;
+    mv[r] = v ? pg[(int64_t)t * 2 * scs + scs] : 0.f;
+    s += sv[r];
+  }
+  for (int t = lane + 64 * R; t < ntile; t += 64) s += pg[(int64_t)t * 2 * scs];
   s = cat::wave_sum(s);
   const float count = (float)Ho * (float)Wo * (float)imgs_per_group;
   const float mean = s / count;
   float m2 = 0.f;
-  for (int t = lane; t < ntile; t += 64) {
+  auto tile_n = [&](int t) {
     const int ti = t % per_img;
     const int ty = ti / tiles_x, tx = ti - ty * tiles_x;
-    const float n = (float)(min(TH, Ho - ty * TH) * min(TW, Wo - tx * TW));
+    return (float)(min(TH, Ho - ty * TH) * min(TW, Wo - tx * TW));
+  };
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int t = lane + 64 * r;
+    if (t < ntile) {
+      const float n = tile_n(t);
+      const float d = sv[r] / n - mean;
+      m2 += mv[r] + n * d * d;
+    }
+  }
+  for (int t = lane + 64 * R; t < ntile; t += 64) {
+    const float n = tile_n(t);
     const float d = pg[(int64_t)t * 2 * scs] / n - mean;
     m2 += pg[(int64_t)t * 2 * scs + scs] + n * d * d;
   }

@@ -38,6 +38,66 @@ struct Launch {
   int nt_total, nblk;      // 16-wide N tiles of the output, N blocks (gridDim.x = N * tiles * nblk)
 };
 
+__device__ __forceinline__ f4 bload(const __amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff_) {
+  const auto r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff_, 0);
+  static_assert(sizeof(r) == sizeof(f4), "buffer load width");
+  return __builtin_bit_cast(f4, r);
+}
+
+// MFMA stream of one staged chunk: ngr groups of 4 (tap, quad) pairs, MT x NT accumulator tiles.  Two operand register sets in
+// ping-pong (no copies); the operands of group g+1 and the A offset of group g+2 are requested BEFORE the 4*MT*NT MFMAs of group g are
+// issued, so no load is waited for in the group that issued it.  tab = this lane quarter's A-offset table, so = byte offset of the
+// chunk's first group in the packed filter stream, gbytes = bytes per group.
+template <int MT, int NT>
+__device__ __forceinline__ void mma_groups(f4 (&acc)[MT][NT], const float* tile, const int* tab, const int (&abase)[MT],
+                                           const __amdgpu_buffer_rsrc_t rsrc, const unsigned (&jb)[NT], unsigned so, unsigned gbytes, int ngr) {
+  const int last = ngr - 1;
+  f4 a0[MT], a1[MT], b0[NT], b1[NT];
+  int off = tab[0];
+  int offn = tab[4 * min(1, last)];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) a0[i] = *reinterpret_cast<const f4*>(tile + abase[i] + off);
+#pragma unroll
+  for (int j = 0; j < NT; ++j) b0[j] = bload(rsrc, jb[j], so);
+  int gi = 0;
+  while (true) {
+    {
+      const int g1 = min(gi + 1, last), g2 = min(gi + 2, last);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) a1[i] = *reinterpret_cast<const f4*>(tile + abase[i] + offn);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) b1[j] = bload(rsrc, jb[j], so + (unsigned)g1 * gbytes);
+      offn = tab[4 * g2];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int tq = 0; tq < 4; ++tq)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i][tq], b0[j][tq], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (++gi >= ngr) break;
+    {
+      const int g1 = min(gi + 1, last), g2 = min(gi + 2, last);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) a0[i] = *reinterpret_cast<const f4*>(tile + abase[i] + offn);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) b0[j] = bload(rsrc, jb[j], so + (unsigned)g1 * gbytes);
+      offn = tab[4 * g2];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int tq = 0; tq < 4; ++tq)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[i][tq], b1[j][tq], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (++gi >= ngr) break;
+  }
+}
+
 template <int NT, int TW>
 __global__ __launch_bounds__(256) void tconv_kernel(const cat_tconv_t g, const float* __restrict__ pack, const float* __restrict__ bias,
                                                     float* __restrict__ y, const Launch L) {
@@ -163,11 +223,6 @@ __global__ __launch_bounds__(256) void tconv_kernel(const cat_tconv_t g, const f
   // packed filters through a buffer resource: per-lane byte offset in voffset, the group's offset in soffset (scalar) -- no vector
   // ALU address arithmetic in the MFMA stream
   const __amdgpu_buffer_rsrc_t prsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pack), 0, 0x7fffffff, 0x00020000);
-  auto bload = [&](unsigned voff, unsigned soff_) {
-    const auto r = __builtin_amdgcn_raw_buffer_load_b128(prsrc, voff, soff_, 0);
-    static_assert(sizeof(r) == sizeof(f4), "buffer load width");
-    return __builtin_bit_cast(f4, r);
-  };
   unsigned jb[NT];   // byte offsets inside one group
 #pragma unroll
   for (int j = 0; j < NT; ++j) jb[j] = (unsigned)(min(j0 + j, L.nt_total - 1) * 64 + lane) * 16u;
@@ -196,59 +251,7 @@ __global__ __launch_bounds__(256) void tconv_kernel(const cat_tconv_t g, const f
     const bool more = ns < g.nseg;
     if (more) gload(ns, nc0);   // in flight behind this chunk's MFMA stream
 
-    {
-      // MFMA stream of this chunk.  Two operand register sets in ping-pong (no copies), the operands of group g+1 and the A offset
-      // of group g+2 are requested BEFORE the 4*MT*NT MFMAs of group g are issued, so no load is waited for in the same group.
-      const float* tile = tile0 + buf * tile_floats;
-      const int* tab = tab0 + buf * TABN + lq;
-      const unsigned gbytes = (unsigned)gstride * 4u;
-      const unsigned so = (unsigned)cpack * 4u;
-      const int last = ngr - 1;
-      f4 a0[MT], a1[MT], b0[NT], b1[NT];
-      int off = tab[0];
-      int offn = tab[4 * min(1, last)];
-#pragma unroll
-      for (int i = 0; i < MT; ++i) a0[i] = *reinterpret_cast<const f4*>(tile + abase[i] + off);
-#pragma unroll
-      for (int j = 0; j < NT; ++j) b0[j] = bload(jb[j], so);
-      int gi = 0;
-      while (true) {
-        {
-          const int g1 = min(gi + 1, last), g2 = min(gi + 2, last);
-#pragma unroll
-          for (int i = 0; i < MT; ++i) a1[i] = *reinterpret_cast<const f4*>(tile + abase[i] + offn);
-#pragma unroll
-          for (int j = 0; j < NT; ++j) b1[j] = bload(jb[j], so + (unsigned)g1 * gbytes);
-          offn = tab[4 * g2];
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int tq = 0; tq < 4; ++tq)
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-              for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i][tq], b0[j][tq], acc[i][j], 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        if (++gi >= ngr) break;
-        {
-          const int g1 = min(gi + 1, last), g2 = min(gi + 2, last);
-#pragma unroll
-          for (int i = 0; i < MT; ++i) a0[i] = *reinterpret_cast<const f4*>(tile + abase[i] + offn);
-#pragma unroll
-          for (int j = 0; j < NT; ++j) b0[j] = bload(jb[j], so + (unsigned)g1 * gbytes);
-          offn = tab[4 * g2];
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int tq = 0; tq < 4; ++tq)
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-              for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[i][tq], b1[j][tq], acc[i][j], 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        if (++gi >= ngr) break;
-      }
-    }
+    mma_groups<MT, NT>(acc, tile0 + buf * tile_floats, tab0 + buf * TABN + lq, abase, prsrc, jb, (unsigned)cpack * 4u, (unsigned)gstride * 4u, ngr);
     if (!more) break;
     sstore(buf ^ 1, ns, nc0);
     __syncthreads();
@@ -348,6 +351,216 @@ __global__ __launch_bounds__(256) void tconv_kernel(const cat_tconv_t g, const f
       }
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------------ fused first convs of a block
+// All first convs of an InvertedResidualChannels block (inception_modules.py:135-147,150-165: the 5x5, the 3x3 and the N-concatenated
+// 1x1 convs of every branch) from ONE staging of the input tile per 16-channel chunk: three accumulator sets (NA / NB / NC 16-wide
+// tiles), three filter streams, outputs = three channel slices of the pre-norm buffer + their per-tile statistics.  The narrow convs
+// alone cannot hide their own staging latency (a 3x3 chunk is ~1 us of MFMA work); together a chunk carries ~7 us.
+struct S1Args {
+  const float* x; const float* pack[3]; const float* bias; float* y; float* stats;
+  int xcs, c4, N, H, W, reflect, ycs, scs;
+  int nt_total[3], col0[3], width[3], nvalid[3];
+  int hl, tr, tc, tiles_x, tiles;
+};
+
+template <int NT>
+__device__ __forceinline__ void s1_epilogue(f4 (&acc)[2][NT], const S1Args& p, int k, int n, int tt, int oy0, int ox0, int wave, int lr, int lq,
+                                            float* red) {
+  const int col0 = p.col0[k], width = p.width[k], nv = width;   // padding columns inside the slice carry zero filters: plain zeros come out
+  const int cnt = min(TH, p.H - oy0) * min(16, p.W - ox0);
+  float s[NT], mean[NT], bv[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int co = j * 16 + lr;
+    bv[j] = (p.bias && co < nv) ? p.bias[col0 + co] : 0.f;
+    float a = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const bool rowv = oy0 + 2 * wave + i < p.H;
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) a += (rowv && ox0 + lq * 4 + rg < p.W) ? acc[i][j][rg] + bv[j] : 0.f;
+    }
+    a += __shfl_xor(a, 16, 64);
+    a += __shfl_xor(a, 32, 64);
+    if (lq == 0) red[wave * NT * 16 + j * 16 + lr] = a;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int c = j * 16 + lr;
+    s[j] = (red[c] + red[NT * 16 + c]) + (red[2 * NT * 16 + c] + red[3 * NT * 16 + c]);
+    mean[j] = s[j] / (float)cnt;
+  }
+  float* red2 = red + 4 * NT * 16;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    float a = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const bool rowv = oy0 + 2 * wave + i < p.H;
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const float d = acc[i][j][rg] + bv[j] - mean[j];
+        a += (rowv && ox0 + lq * 4 + rg < p.W) ? d * d : 0.f;
+      }
+    }
+    a += __shfl_xor(a, 16, 64);
+    a += __shfl_xor(a, 32, 64);
+    if (lq == 0) red2[wave * NT * 16 + j * 16 + lr] = a;
+  }
+  __syncthreads();
+  if (wave == 0 && lq == 0) {
+    float* dst = p.stats + (int64_t)tt * 2 * p.scs + col0;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int c = j * 16 + lr;
+      if (c < width) {
+        const bool cv = c < nv;
+        dst[c] = cv ? s[j] : 0.f;
+        dst[p.scs + c] = cv ? (red2[c] + red2[NT * 16 + c]) + (red2[2 * NT * 16 + c] + red2[3 * NT * 16 + c]) : 0.f;
+      }
+    }
+  }
+  __syncthreads();   // red is reused by the next sub-convolution
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int oy = oy0 + 2 * wave + i;
+    if (oy >= p.H) continue;
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      const int ox = ox0 + lq * 4 + rg;
+      if (ox >= p.W) continue;
+      float* yo = p.y + (((int64_t)n * p.H + oy) * p.W + ox) * p.ycs + col0;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int co = j * 16 + lr;
+        if (co < nv) yo[co] = acc[i][j][rg] + bv[j];
+        else if (co < width) yo[co] = 0.f;
+      }
+    }
+  }
+}
+
+template <int NA, int NB, int NC>
+__global__ __launch_bounds__(256) void tstage1_kernel(const S1Args p) {
+  constexpr int MT = 2, TW = 16, MAXIT = ((TH + 4) * (TW + 4) * 4 + 255) / 256;
+  constexpr int NMAX = NA > NB ? (NA > NC ? NA : NC) : (NB > NC ? NB : NC);
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tile_floats = p.tr * p.tc * PITCH;
+  float* tile0 = smem;
+  int* tab0 = reinterpret_cast<int*>(smem + 2 * tile_floats);      // [buf][3][TABN]
+  float* red = smem + 2 * tile_floats + 6 * TABN;                  // [2][4][NMAX * 16]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lq = lane >> 4;
+  const int tt = cat::xcd_remap(blockIdx.x, gridDim.x);
+  const int n = tt / p.tiles, t = tt - n * p.tiles;
+  const int oy0 = (t / p.tiles_x) * TH, ox0 = (t % p.tiles_x) * TW;
+  const int slots = p.tr * p.tc * 4, quad = tid & 3;
+  unsigned soff[MAXIT], smask = 0;
+#pragma unroll
+  for (int it = 0; it < MAXIT; ++it) {
+    const int pix = (tid + it * 256) >> 2;
+    const int r = pix / p.tc;
+    int iy = oy0 - p.hl + r, ix = ox0 - p.hl + (pix - r * p.tc);
+    bool v = tid + it * 256 < slots;
+    if (p.reflect) {
+      v = v && iy > -p.H && iy < 2 * p.H - 1 && ix > -p.W && ix < 2 * p.W - 1;
+      iy = cat::reflect_idx(iy, p.H);
+      ix = cat::reflect_idx(ix, p.W);
+    } else {
+      v = v && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+    }
+    smask |= v ? (1u << it) : 0u;
+    soff[it] = v ? ((unsigned)(n * p.H + iy) * (unsigned)p.W + (unsigned)ix) * (unsigned)p.xcs + quad * 4 : 0u;
+  }
+  f4 sreg[MAXIT];
+  auto gload = [&](int c0) {
+    const bool qv = c0 + quad * 4 < p.c4;
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) sreg[it] = *reinterpret_cast<const f4*>((((smask >> it) & 1u) && qv) ? p.x + soff[it] + c0 : g_zero);
+  };
+  auto sstore = [&](int buf, int c0) {
+    float* tile = tile0 + buf * tile_floats;
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+      const int idx = tid + it * 256;
+      if (idx < slots) *reinterpret_cast<f4*>(tile + (idx >> 2) * PITCH + quad * 4) = sreg[it];
+    }
+    const int nq = min(4, (p.c4 - c0) >> 2);
+    if (tid < TABN) {
+      const int tap = tid / nq, qd = tid - tap * nq;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int ks = k == 0 ? 5 : (k == 1 ? 3 : 1), taps = ks * ks;
+        int off = 0;
+        if (tid < ((taps * nq + 3) >> 2) * 4 && tap < taps) {
+          const int ky = tap / ks, kx = tap - ky * ks, d = p.hl - (ks >> 1);
+          off = ((d + ky) * p.tc + d + kx) * PITCH + qd * 4;
+        }
+        tab0[(buf * 3 + k) * TABN + tid] = off;
+      }
+    }
+  };
+  f4 accA[MT][NA > 0 ? NA : 1], accB[MT][NB > 0 ? NB : 1], accC[MT][NC > 0 ? NC : 1];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+#pragma unroll
+    for (int j = 0; j < (NA > 0 ? NA : 1); ++j) accA[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < (NB > 0 ? NB : 1); ++j) accB[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < (NC > 0 ? NC : 1); ++j) accC[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+  }
+  int abase[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) abase[i] = ((2 * wave + i) * p.tc + lr) * PITCH;
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.pack[0]), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.pack[1]), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.pack[2]), 0, 0x7fffffff, 0x00020000);
+  unsigned jbA[NA > 0 ? NA : 1], jbB[NB > 0 ? NB : 1], jbC[NC > 0 ? NC : 1];
+#pragma unroll
+  for (int j = 0; j < (NA > 0 ? NA : 1); ++j) jbA[j] = (unsigned)(min(j, max(p.nt_total[0], 1) - 1) * 64 + lane) * 16u;
+#pragma unroll
+  for (int j = 0; j < (NB > 0 ? NB : 1); ++j) jbB[j] = (unsigned)(min(j, max(p.nt_total[1], 1) - 1) * 64 + lane) * 16u;
+#pragma unroll
+  for (int j = 0; j < (NC > 0 ? NC : 1); ++j) jbC[j] = (unsigned)(min(j, max(p.nt_total[2], 1) - 1) * 64 + lane) * 16u;
+  unsigned soA = 0, soB = 0, soC = 0;     // byte offsets of the current chunk in the three streams
+  gload(0);
+  sstore(0, 0);
+  __syncthreads();
+  int buf = 0;
+  for (int c0 = 0; c0 < p.c4; c0 += 16) {
+    const bool more = c0 + 16 < p.c4;
+    if (more) gload(c0 + 16);
+    const int nq = min(4, (p.c4 - c0) >> 2);
+    const float* tile = tile0 + buf * tile_floats;
+    const int* tab = tab0 + buf * 3 * TABN + lq;
+    if constexpr (NA > 0) {
+      const int ngr = (25 * nq + 3) >> 2;
+      mma_groups<MT, NA>(accA, tile, tab, abase, rA, jbA, soA, (unsigned)p.nt_total[0] * 1024u, ngr);
+      soA += (unsigned)ngr * p.nt_total[0] * 1024u;
+    }
+    if constexpr (NB > 0) {
+      const int ngr = (9 * nq + 3) >> 2;
+      mma_groups<MT, NB>(accB, tile, tab + TABN, abase, rB, jbB, soB, (unsigned)p.nt_total[1] * 1024u, ngr);
+      soB += (unsigned)ngr * p.nt_total[1] * 1024u;
+    }
+    if constexpr (NC > 0) {
+      mma_groups<MT, NC>(accC, tile, tab + 2 * TABN, abase, rC, jbC, soC, (unsigned)p.nt_total[2] * 1024u, 1);
+      soC += (unsigned)p.nt_total[2] * 1024u;
+    }
+    if (more) {
+      sstore(buf ^ 1, c0 + 16);
+      __syncthreads();
+      buf ^= 1;
+    }
+  }
+  __syncthreads();
+  if constexpr (NA > 0) s1_epilogue<NA>(accA, p, 0, n, tt, oy0, ox0, wave, lr, lq, red);
+  if constexpr (NB > 0) s1_epilogue<NB>(accB, p, 1, n, tt, oy0, ox0, wave, lr, lq, red);
+  if constexpr (NC > 0) s1_epilogue<NC>(accC, p, 2, n, tt, oy0, ox0, wave, lr, lq, red);
 }
 
 // dst[(G * nt_total + j) * 256 + lane * 4 + e]: G enumerates the MFMA groups of all chunks of one segment in consumption order
@@ -478,6 +691,52 @@ int cat_tconv_fwd(const cat_tconv_t* g, const float* pack, const float* bias, fl
 #undef CAT_PK_NT
 #undef CAT_PK_LAUNCH
   return cat::check_launch("tconv_fwd");
+}
+
+int cat_tstage1_fwd(const cat_tstage1_t* g, const float* x, const float* const* packs, const float* bias, float* y, float* stats,
+                    cat_stream_t stream) {
+  CAT_REQUIRE(g->N > 0 && g->H > 0 && g->W > 0 && g->cin > 0 && (g->xcs & 3) == 0 && g->xcs >= g->cin, "tstage1: bad input geometry");
+  CAT_REQUIRE(y && stats && (g->ycs & 3) == 0 && (g->scs & 3) == 0, "tstage1: output / statistics buffers");
+  CAT_REQUIRE((int64_t)g->N * g->H * g->W * g->xcs < (int64_t)4294967295LL, "tstage1: source larger than 2^32 elements");
+  cat_pk::S1Args a{};
+  a.x = x; a.bias = bias; a.y = y; a.stats = stats;
+  a.xcs = g->xcs; a.c4 = (g->cin + 3) & ~3; a.N = g->N; a.H = g->H; a.W = g->W; a.reflect = g->reflect; a.ycs = g->ycs; a.scs = g->scs;
+  int nt[3];
+  double kflops = 0.0;
+  for (int k = 0; k < 3; ++k) {
+    nt[k] = g->width[k] > 0 ? cat::cdiv(g->width[k], 16) : 0;
+    a.pack[k] = nt[k] ? packs[k] : x;     // a valid address for the (unused) buffer resource
+    a.nt_total[k] = nt[k]; a.col0[k] = g->col0[k]; a.width[k] = g->width[k]; a.nvalid[k] = g->nvalid[k];
+    CAT_REQUIRE(nt[k] == 0 || (packs[k] && g->col0[k] + g->width[k] <= g->ycs && g->nvalid[k] <= g->width[k]), "tstage1: slice %d", k);
+    const int ks = k == 0 ? 5 : (k == 1 ? 3 : 1);
+    kflops += (double)g->nvalid[k] * ks * ks;
+  }
+  a.hl = nt[0] ? 2 : (nt[1] ? 1 : 0);
+  CAT_REQUIRE(!g->reflect || (2 * a.hl + 1 <= g->H && 2 * a.hl + 1 <= g->W), "tstage1: reflect padding wider than the plane");
+  a.tr = cat_pk::TH + 2 * a.hl;
+  a.tc = 16 + 2 * a.hl;
+  a.tiles_x = cat::cdiv(g->W, 16);
+  a.tiles = a.tiles_x * cat::cdiv(g->H, cat_pk::TH);
+  const int64_t grid = (int64_t)g->N * a.tiles;
+  const int nmax = nt[0] > nt[1] ? (nt[0] > nt[2] ? nt[0] : nt[2]) : (nt[1] > nt[2] ? nt[1] : nt[2]);
+  const size_t lds = (size_t)2 * a.tr * a.tc * cat_pk::PITCH * sizeof(float) + 6 * cat_pk::TABN * sizeof(int) + (size_t)8 * nmax * 16 * sizeof(float);
+  hipStream_t s = (hipStream_t)stream;
+  cat::ProfScope prof("conv_tstage1", 2.0 * (double)g->N * g->H * g->W * g->cin * kflops, 0.0, stream);
+#define CAT_S1(NA, NB, NC)                                                                        \
+  if (nt[0] == NA && nt[1] == NB && nt[2] == NC) {                                                \
+    cat_pk::tstage1_kernel<NA, NB, NC><<<(int)grid, 256, lds, s>>>(a);                            \
+    return cat::check_launch("tstage1_fwd");                                                      \
+  }
+  CAT_S1(1, 1, 2) CAT_S1(1, 1, 3) CAT_S1(1, 1, 4) CAT_S1(2, 1, 2) CAT_S1(2, 1, 3) CAT_S1(2, 1, 4)
+  CAT_S1(1, 2, 2) CAT_S1(1, 2, 3) CAT_S1(1, 2, 4) CAT_S1(2, 2, 2) CAT_S1(2, 2, 3) CAT_S1(2, 2, 4)
+#undef CAT_S1
+  cat::set_error("tstage1: no kernel for %d / %d / %d N tiles (cat_tstage1_supported)", nt[0], nt[1], nt[2]);
+  return -22;
+}
+
+int cat_tstage1_supported(int w5, int w3, int w1) {
+  const int a = cat::cdiv(w5, 16), b = cat::cdiv(w3, 16), c = cat::cdiv(w1, 16);
+  return w5 > 0 && w3 > 0 && w1 > 0 && a <= 2 && b <= 2 && c >= 2 && c <= 4;
 }
 
 }  // extern "C"

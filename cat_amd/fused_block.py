@@ -303,12 +303,24 @@ def forward(block, x, save=None):
     # ---- stage 1: first convs -> Z1 (pre-norm, concatenated) + tile statistics
     z1 = torch.empty((n, h, w, p.hc1), device=dev, dtype=torch.float32)
     part1 = torch.empty((tiles, 2, p.hc1), device=dev, dtype=torch.float32)
-    for g in p.groups:
-        pad = (g['k'] - 1) // 2
-        seg = tconv.Segment(x, g['k'], pad, p.reflect and pad > 0, 0)
-        tconv.run([seg], g['pack'], (p.bias1.data_ptr() + 4 * g['off']) if p.has_bias1 else None, None, g['width'], n, h, w, h, w, ycs=p.hc1,
-                  ycw=g['width'], yptr=z1.data_ptr() + 4 * g['off'], stats=part1.data_ptr() + 4 * g['off'], scs=p.hc1,
-                  nvalid=sum(b['m'] for b in g['branches']))
+    by_k = {g['k']: g for g in p.groups}
+    if len(p.groups) == 3 and L.query('cat_tstage1_supported', by_k[5]['width'], by_k[3]['width'], by_k[1]['width']):
+        # one launch: the three kernel sizes share every staged input tile
+        gs = L.Stage1Geom()
+        gs.N, gs.H, gs.W, gs.xcs, gs.cin, gs.reflect, gs.ycs, gs.scs = n, h, w, ops.act_cs(x), c, int(p.reflect), p.hc1, p.hc1
+        packs = (C.c_void_p * 3)()
+        for slot, k in enumerate((5, 3, 1)):
+            g = by_k[k]
+            gs.col0[slot], gs.width[slot], gs.nvalid[slot] = g['off'], g['width'], sum(b['m'] for b in g['branches'])
+            packs[slot] = g['pack'].data_ptr()
+        L.call('cat_tstage1_fwd', C.byref(gs), ops._p(x), packs, ops._p(p.bias1) if p.has_bias1 else None, ops._p(z1), ops._p(part1), ops._stream())
+    else:
+        for g in p.groups:
+            pad = (g['k'] - 1) // 2
+            seg = tconv.Segment(x, g['k'], pad, p.reflect and pad > 0, 0)
+            tconv.run([seg], g['pack'], (p.bias1.data_ptr() + 4 * g['off']) if p.has_bias1 else None, None, g['width'], n, h, w, h, w, ycs=p.hc1,
+                      ycw=g['width'], yptr=z1.data_ptr() + 4 * g['off'], stats=part1.data_ptr() + 4 * g['off'], scs=p.hc1,
+                      nvalid=sum(b['m'] for b in g['branches']))
     st1 = _finalize(p, part1, p.hc1, n, h, w, p.gamma1, p.beta1, [(b['o1'], b['m'], b['bn1']) for b in p.branches])
     # ---- depthwise stage
     zd = std = None

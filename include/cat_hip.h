@@ -344,6 +344,21 @@ typedef struct {
 } cat_prep_job_t;
 int cat_prep_run(const cat_prep_job_t* jobs_dev, int njobs, int total_blocks, int accumulate, cat_stream_t stream);
 
+/* All first convs of a block in one launch (csrc/conv_pk.hip tstage1_kernel): the 5 x 5 conv (slot 0), the 3 x 3 conv (slot 1) and the
+ * N-concatenated 1 x 1 convs (slot 2) of InvertedResidualChannels (inception_modules.py:135-147,150-165) share ONE staging of the
+ * input tile per 16-channel chunk; each writes its channel slice [col0, col0 + width) of the pre-norm buffer y (no activation) and its
+ * per-tile statistics (layout as cat_tconv_fwd `stats`).  packs[k]: the slot's filter stream (cat_prep_run kind 0 / cat_tconv_pack with
+ * Nn = width); bias: concatenated over y's columns or NULL.  cat_tstage1_supported tells whether a kernel exists for the widths. */
+typedef struct {
+  int N, H, W, xcs, cin;
+  int reflect;
+  int ycs, scs;
+  int col0[3], width[3], nvalid[3];
+} cat_tstage1_t;
+int cat_tstage1_supported(int w5, int w3, int w1);
+int cat_tstage1_fwd(const cat_tstage1_t* g, const float* x, const float* const* packs, const float* bias, float* y, float* stats,
+                    cat_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
