@@ -378,11 +378,17 @@ __global__ __launch_bounds__(256) void prep_kernel(const cat_prep_job_t* __restr
     const int c = (int)(e / taps), tp = (int)(e - (int64_t)c * taps);
     const int ky = tp / J.ks, kx = tp - ky * J.ks, o = 2 - (J.ks >> 1);
     J.dst[((o + ky) * 5 + o + kx) * J.cs + J.col0 + c] = J.srcs[0][e];
-  } else {                    // scatter a slice of a concatenated gradient vector to its parameter
+  } else if (J.kind == 3) {   // scatter a slice of a concatenated gradient vector to its parameter
     if (e >= J.n) return;
     float* d = const_cast<float*>(J.srcs[1]);
     const float v = J.srcs[0][e];
     d[e] = accumulate ? d[e] + v : v;
+  } else {                    // kind 4: 2-D scatter, dst[r * wcs + i] (+)= src[r * wn + i], i < cs (columns of a K-concatenated weight gradient)
+    if (e >= J.n) return;
+    const int r = (int)(e / J.cs), i = (int)(e - (int64_t)r * J.cs);
+    float* d = const_cast<float*>(J.srcs[1]) + (int64_t)r * J.wcs + i;
+    const float v = J.srcs[0][(int64_t)r * J.wn + i];
+    *d = accumulate ? *d + v : v;
   }
 }
 

@@ -333,7 +333,8 @@ int cat_dwm_fwd(const cat_dwm_t* g, const float* x, const float* scale, const fl
  *           first convs; mode as cat_tconv_pack)
  *   kind 1  dst[i] = sum_k srcs[k][i], i < n     (concatenated gamma / beta / bias vectors; the summed bias of the branch sum)
  *   kind 2  depthwise filter [C][ks][ks] -> dst[tap25][cs] 5 x 5 frame, channels [col0, col0 + C)
- *   kind 3  dsts[k][i] (+)= src[i], i < n         (scatter a concatenated parameter gradient back; accumulate = cat_prep_run's flag) */
+ *   kind 3  srcs[1][i] (+)= srcs[0][i], i < n     (scatter a concatenated parameter gradient back; accumulate = cat_prep_run's flag)
+ *   kind 4  srcs[1][r*wcs + i] (+)= srcs[0][r*wn + i], i < cs, r < n / cs   (columns of a K-concatenated weight gradient) */
 #define CAT_PREP_MAXSRC 8
 typedef struct {
   const float* srcs[CAT_PREP_MAXSRC];
