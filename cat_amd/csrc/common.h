@@ -40,16 +40,6 @@ int smallco_fwd(const cat_conv_t* g, const float* x, const float* w, const float
 int smallco_wgrad_nblk(const cat_conv_t* g);
 int smallco_wgrad(const cat_conv_t* g, const float* x, const float* dy, float* ws, hipStream_t s);
 
-// narrow-output stride-1 3x3 / 5x5 forward from an LDS-resident input tile (conv_tile.hip); opt-in via CAT_CONV_TILE=1
-bool conv_tile_applicable(const cat_conv_t* g);
-int conv_tile_fwd(const cat_conv_t* g, const float* x, const float* w, const float* bias, float* y, hipStream_t s);
-bool conv_tile_dgrad_applicable(const cat_conv_t* g, int dxcw);
-int conv_tile_dgrad(const cat_conv_t* g, const float* dy, const float* w, const float* bias, float* dx, int dxcs, int dxcw, hipStream_t s);
-
-bool conv_tile_wgrad_applicable(const cat_conv_t* g);
-int conv_tile_wgrad_nsplit(const cat_conv_t* g);
-int conv_tile_wgrad(const cat_conv_t* g, const float* x, const float* dy, float* ws, hipStream_t s);   // partials [nsplit][Cout][taps*c4]
-
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 

@@ -1268,7 +1268,7 @@ size_t cat_conv2d_fwd_ws_bytes(const cat_conv_t* g) {
     const int ks = cat::smallco_fwd_ksplit(g);
     return ks > 1 ? (size_t)ks * a.M * g->ycs * sizeof(float) : 0;
   }
-  if (cat::conv_tile_applicable(g) || !fwd_bk32_ok(a)) return 0;
+  if (!fwd_bk32_ok(a)) return 0;
   const SplitPlan sp = split_plan(a.M, a.Cout, (a.K + 31) >> 5);
   return sp.ksplit > 1 ? (size_t)sp.ksplit * a.M * g->ycs * sizeof(float) : 0;
 }
@@ -1304,10 +1304,6 @@ static int conv_fwd_impl(const cat_conv_t* g, const float* x, const float* w, co
     return 0;
   }
   const double prof_flops = 2.0 * (double)g->N * g->Ho * g->Wo * g->Cout * g->kh * g->kw * g->Cin;
-  if (cat::conv_tile_applicable(g)) {
-    cat::ProfScope prof("conv_fwd_tile", prof_flops, 0.0, stream);
-    return cat::conv_tile_fwd(g, x, w, bias, y, s);
-  }
   static const int sched = getenv("CAT_SCHED") ? atoi(getenv("CAT_SCHED")) : 0;
   static const int lds_pad = getenv("CAT_LDS_PAD") ? atoi(getenv("CAT_LDS_PAD")) : 0;  // diagnostics: caps workgroups/CU
   static long long* dbg_buf = nullptr;
@@ -1437,10 +1433,6 @@ static int conv_dgrad_impl(const cat_conv_t* g, const float* dy, const float* w,
                                                                             a.slope);      \
     }                                                                                      \
   }
-  if (a.ksplit == 1 && cat::conv_tile_dgrad_applicable(g, dxcw)) {
-    cat::ProfScope prof("conv_dgrad_tile", prof_flops, 0.0, stream);
-    return cat::conv_tile_dgrad(g, dy, w, bias, dx, dxcs, dxcw, s);
-  }
   // BK = 32 variant of the 128 x 128 tile (the discriminator's and the teacher's wide layers)
   static const int bk32 = getenv("CAT_DGRAD_BK32") ? atoi(getenv("CAT_DGRAD_BK32")) : 1;
   if (bk32 && a.ksplit == 1 && a.Cin > 96 && a.wvec && g->Cout % 16 == 0 && g->Cin % 4 == 0) {
@@ -1465,7 +1457,6 @@ size_t cat_conv2d_wgrad_ws_bytes(const cat_conv_t* g) {
   const WgradPlan pl = wgrad_plan(g);
   const size_t K = (size_t)g->kh * g->kw * ((g->Cin + 3) & ~3);
   if (cat::smallco_applicable(g)) return (size_t)cat::smallco_wgrad_nblk(g) * g->Cout * K * sizeof(float);
-  if (cat::conv_tile_wgrad_applicable(g)) return (size_t)cat::conv_tile_wgrad_nsplit(g) * g->Cout * K * sizeof(float);
   return (size_t)pl.nsplit * g->Cout * K * sizeof(float);
 }
 
@@ -1495,15 +1486,6 @@ int cat_conv2d_wgrad(const cat_conv_t* g, const float* x, const float* dy, float
     return cat::check_launch("conv2d_wgrad_reduce");
   }
   const double prof_flops = 2.0 * (double)g->N * g->Ho * g->Wo * g->Cout * g->kh * g->kw * g->Cin;
-  if (cat::conv_tile_wgrad_applicable(g)) {
-    CAT_REQUIRE(ws != nullptr, "conv wgrad: workspace required");
-    cat::ProfScope prof("conv_wgrad_tile", prof_flops, 0.0, stream);
-    if (int e = cat::conv_tile_wgrad(g, x, dy, (float*)ws, s)) return e;
-    const int64_t total = (int64_t)a.Cout * a.kh * a.kw * a.cval;
-    wgrad_reduce_kernel<<<(int)((total + 63) / 64), 256, 0, s>>>((const float*)ws, dw, cat::conv_tile_wgrad_nsplit(g), a.Cout, a.kh * a.kw,
-                                                                  a.cval, a.wcs, a.c4, a.K, accumulate);
-    return cat::check_launch("conv2d_wgrad_reduce");
-  }
   CAT_REQUIRE(a.direct || ws != nullptr, "conv wgrad: workspace required");
 #define LAUNCH(MT, NT, WM, WN)                                                                         \
   {                                                                                                    \

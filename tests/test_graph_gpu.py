@@ -95,3 +95,39 @@ def test_graph_replay_equals_eager_spade():
     me, mg = eager.modules_on_one_gpu, graphed.modules_on_one_gpu
     assert _max_param_diff(mg.netG_student, me.netG_student) < 1e-5
     assert _max_param_diff(mg.netD, me.netD) < 1e-5
+
+
+@pytest.mark.parametrize('fused', [False, True])
+def test_step_contains_only_library_kernels(fused):
+    """Every device activity of one optimize_parameters is a libcat_hip kernel: no ATen elementwise / reduction kernel, no
+    memcpy / memset node (what torch.profiler sees through roctracer, which is also what a captured hipGraph would hold)."""
+    from torch.profiler import ProfilerActivity, profile
+    from cat_amd import ops
+    g = H.load('step_bn.npz')
+    meta = json.loads(str(g['meta']))
+    opt = H.make_opt(norm=meta['norm'], track=meta['track'], ndf=meta['ndf'], dataset_mode=meta['dataset_mode'], gan_mode=meta['gan_mode'],
+                     lambda_recon=meta['lambda_recon'], lambda_distill=meta['lambda_distill'], student_ngf=16)
+    old = ops.set_tconv_min_tiles(1 if fused else 1 << 30)      # with / without the LDS-tile + fused-block kernels on this 64 x 64 batch
+    try:
+        model = H.build_distiller(opt, g['student_shapes'])
+        n, s = meta['nbatch'], meta['size']
+        b = {'A': detfill.images((n, 3, s, s), 1).cuda(), 'B': detfill.images((n, 3, s, s), 2).cuda(), 'A_paths': [], 'B_paths': []}
+        for i in range(2):
+            model.set_input(b)
+            model.optimize_parameters(i)
+        torch.cuda.synchronize()
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            model.set_input(b)
+            model.optimize_parameters(2)
+            torch.cuda.synchronize()
+    finally:
+        ops.set_tconv_min_tiles(old)
+    names = {}
+    for e in prof.events():
+        if e.device_type == torch.autograd.DeviceType.CUDA:
+            names[e.name] = names.get(e.name, 0) + 1
+    assert len(names) > 30, names
+    foreign = {k: v for k, v in names.items() if not ('(anonymous namespace)::' in k or 'cat_' in k)}
+    assert not foreign, foreign
+    if fused:
+        assert any('tconv_kernel' in k for k in names) and any('tnorm_finalize' in k for k in names), sorted(names)
