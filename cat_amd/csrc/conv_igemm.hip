@@ -462,6 +462,138 @@ __global__ __launch_bounds__(256) void conv_fwd32_kernel(IgemmArgs p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------ forward, BK = 32, direct-to-LDS staging
+// conv_fwd32_kernel's 128 x 128 x 32 tiling with the operand tiles DMA-ed straight into LDS (buffer_load_dwordx4 ... lds): no staging
+// VGPRs, no ds_write pass, and -- because the per-lane part of every address is a 32-bit voffset that only changes when the walk moves to
+// the next filter tap, while the advance along the channels is an SGPR soffset -- no vector-ALU address arithmetic in the steady state.
+// (On gfx950 the fp32 MFMA shares its issue slots with the vector ALU: 8 loads + 8 ds_write_b128 + ~40 VALU per 128 MFMAs cost the
+// register-staged kernel ~15 % of the matrix pipe.)  A lane-linear LDS image is what the DMA writes, so the XOR swizzle of the [row][32 k]
+// tiles is applied to the SOURCE quad each lane fetches (guide rule 21); the fragment reads keep conv_fwd32_kernel's swz32.
+// Out-of-image / padding / tail lanes carry voffset 0x80000000: beyond num_records, the buffer unit returns zeros.
+// Preconditions (host): Cin % 32 == 0 (a 32-chunk never straddles taps), float4-readable filters, tensors < 2 GB.
+template <int WMW>   // dummy parameter keeps the kernel a template like its siblings (2 x 2 waves of 4 x 4 MFMA tiles)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_fwd32d_kernel(IgemmArgs p) {
+  constexpr int MT = 4, NT = 4, WN = 2, BM = 128, BN = 128;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  typedef __attribute__((address_space(3))) void* lds_t;
+  float* sA = smem;
+  float* sB = smem + 2 * BM * 32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int ntn = (p.Cout + BN - 1) / BN;
+  const int bid = cat::xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (bid / ntn) * BM, n0 = (bid % ntn) * BN;
+  const int HoWo = p.Ho * p.Wo, taps = p.kh * p.kw;
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.b), 0, 0x7fffffff, 0x00020000);
+  // staging map: wave w, instruction i -> rows (w * 4 + i) * 8 + (lane >> 3) of the tile, LDS slot lane & 7 <- source quad slot ^ swz(row)
+  const int slot = lane & 7, lrow = lane >> 3;
+  int iy0[4], ix0[4];
+  unsigned abase[4], aq[4], voffA[4], voffB[4];
+  bool rv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (wave * 4 + i) * 8 + lrow;
+    const unsigned q = (unsigned)(slot ^ ((row >> 1) & 7));
+    const int m = m0 + row;
+    rv[i] = m < p.M;
+    const int mm = rv[i] ? m : 0;
+    const int n = mm / HoWo, rem = mm - n * HoWo;
+    const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+    iy0[i] = oy * p.stride - p.pad;
+    ix0[i] = ox * p.stride - p.pad;
+    abase[i] = (unsigned)n * (unsigned)(p.H * p.W) * (unsigned)p.xcs * 4u;
+    aq[i] = q * 16u;
+    const int co = n0 + row;
+    voffB[i] = co < p.Cout ? (unsigned)co * (unsigned)(taps * p.wcs) * 4u + q * 16u : 0x80000000u;
+  }
+  auto locate = [&](int ky, int kx) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int iy = iy0[i] + ky, ix = ix0[i] + kx;
+      const bool inr = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      const int ry = cat::reflect_idx(iy, p.H), rx = cat::reflect_idx(ix, p.W);
+      iy = p.reflect ? ry : (inr ? iy : 0);
+      ix = p.reflect ? rx : (inr ? ix : 0);
+      const bool v = rv[i] && (p.reflect || inr);
+      voffA[i] = v ? abase[i] + (unsigned)(iy * p.W + ix) * (unsigned)p.xcs * 4u + aq[i] : 0x80000000u;
+    }
+  };
+  int tap = 0, ky = 0, kx = 0, ci = 0;      // walk state of the NEXT chunk to fetch (wave-uniform)
+  locate(0, 0);
+  auto issue = [&](int buf) {
+    const unsigned soA = (unsigned)ci * 4u, soB = (unsigned)(tap * p.wcs + ci) * 4u;
+    float* dA = sA + buf * BM * 32 + wave * 4 * 256;
+    float* dB = sB + buf * BN * 32 + wave * 4 * 256;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_t)(dA + i * 256), 16, voffA[i], soA, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_t)(dB + i * 256), 16, voffB[i], soB, 0, 0);
+    ci += 32;
+    if (ci >= p.c4) {      // next tap (wave-uniform, once per Cin / 32 chunks)
+      ci = 0;
+      ++tap;
+      if (++kx == p.kw) {
+        kx = 0;
+        ++ky;
+      }
+      if (tap < taps) locate(ky, kx);
+    }
+  };
+  const int lr = lane & 15, lq = lane >> 4;
+  f4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+  auto mma = [&](int buf) {
+    const float* A = sA + buf * BM * 32;
+    const float* B = sB + buf * BN * 32;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      f4 fa[MT], fb[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const f4*>(A + swz32(wm * MT * 16 + i * 16 + lr, lq + 4 * h));
+#pragma unroll
+      for (int j = 0; j < NT; ++j) fb[j] = *reinterpret_cast<const f4*>(B + swz32(wn * NT * 16 + j * 16 + lr, lq + 4 * h));
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][t], fb[j][t], acc[i][j], 0, 0, 0);
+    }
+  };
+  const int nk = taps * (p.c4 >> 5);
+  issue(0);
+  __builtin_amdgcn_s_waitcnt(0);     // vmcnt(0): the DMA has landed
+  __syncthreads();
+  for (int kc = 0; kc + 1 < nk; ++kc) {
+    const int buf = kc & 1;
+    issue(buf ^ 1);                   // in flight behind this chunk's MFMA stream; buf ^ 1 was released by the barrier below
+    mma(buf);
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+  }
+  mma((nk - 1) & 1);
+
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int col = n0 + wn * NT * 16 + j * 16 + lr;
+    const bool cvalid = col < p.Cout;
+    const float bias = (cvalid && p.bias) ? p.bias[col] : 0.f;
+    if (!cvalid && col >= p.cw) continue;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int m = m0 + wm * MT * 16 + i * 16 + lq * 4 + rg;
+        if (m < p.M) p.out[(int64_t)m * p.ycs + col] = cvalid ? cat::apply_act(acc[i][j][rg] + bias, p.act, p.slope) : 0.f;
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ dgrad
 // blockIdx.y = parity class (py, px) of the forward stride.  N dimension = Cin, K = taps(class) * cout4.
 template <int MT, int NT, int WM, int WN>
@@ -1345,6 +1477,21 @@ static int conv_fwd_impl(const cat_conv_t* g, const float* x, const float* w, co
     if (a.ksplit > 1)                                                                                 \
       splitk_reduce_kernel<<<reduce_grid((int64_t)a.M * ((a.cw + 3) / 4)), 256, 0, s>>>(a.part, a.bias, a.out, a.M, a.Cout, a.cw, a.ycs,   \
                                                                                          a.ksplit, a.act, a.slope);                    \
+  }
+  // direct-to-LDS variant of the 128 x 128 tile: Cin % 32 == 0 (a chunk never straddles taps), no K split, 32-bit byte offsets
+  static const int fwd_direct = getenv("CAT_FWD_DIRECT") ? atoi(getenv("CAT_FWD_DIRECT")) : 1;
+  if (fwd_direct && bk32 && a.ksplit == 1 && a.Cout > 96 && (g->Cin & 31) == 0 && a.c4 == g->Cin && a.wcs >= g->Cin &&
+      (int64_t)g->N * g->H * g->W * g->xcs * 4 < (int64_t)2147483647 && (int64_t)g->Cout * g->kh * g->kw * a.wcs * 4 < (int64_t)2147483647) {
+    cat::ProfScope prof("conv_fwd32d_4x4x2x2", prof_flops, 0.0, stream);
+    const int grid = cdiv(a.M, 128) * cdiv(a.Cout, 128);
+    const size_t lds = (size_t)2 * (128 + 128) * 32 * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)conv_fwd32d_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr_set = true;
+    }
+    conv_fwd32d_kernel<2><<<grid, 256, lds, s>>>(a);
+    return cat::check_launch("conv2d_fwd");
   }
   const bool smallm = use_small_m(a.M, a.Cout);
   if (bk32) {
