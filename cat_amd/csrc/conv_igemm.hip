@@ -1036,6 +1036,150 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
 }
 
+// ------------------------------------------------------------------------------------------------ dgrad, BK = 32, direct-to-LDS staging
+// conv_dgrad32_kernel with both operand tiles DMA-ed into LDS (see conv_fwd32d_kernel).  A = dy rows ([class pixel][32 k], source quad
+// pre-swizzled); B = the filter slab [32 k][128 input channels], whose per-lane voffset NEVER changes: k = (class tap, filter co) only moves
+// the SGPR soffset (+32 filters per chunk, a new tap offset when co wraps).  The 16-column-group XOR of the N-contiguous tile is applied
+// to the source column each lane fetches.  Preconditions (host): Cout % 32 == 0, Cin % 4 == 0, float4-readable filters, tensors < 2 GB.
+template <int WMW>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_dgrad32d_kernel(IgemmArgs p) {
+  constexpr int MT = 4, NT = 4, WN = 2, BM = 128, BN = 128;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  typedef __attribute__((address_space(3))) void* lds_t;
+  float* sA = smem;
+  float* sB = smem + 2 * BM * 32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int s = p.stride;
+  const int py = blockIdx.y / s, px = blockIdx.y % s;
+  const int iyf = ((py - p.pad_eff) % s + s) % s, ixf = ((px - p.pad_eff) % s + s) % s;
+  const int Hc = iyf < p.Hin ? (p.Hin - iyf + s - 1) / s : 0, Wc = ixf < p.Win ? (p.Win - ixf + s - 1) / s : 0;
+  const int cy0 = (iyf + p.pad_eff - py) / s, cx0 = (ixf + p.pad_eff - px) / s;
+  const int nty = py < p.kh ? (p.kh - py + s - 1) / s : 0, ntx = px < p.kw ? (p.kw - px + s - 1) / s : 0;
+  const int ntaps = nty * ntx;
+  const int Mc = p.N * Hc * Wc;
+  const int ntn = (p.Cin + BN - 1) / BN;
+  const int bid = cat::xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (bid / ntn) * BM, n0 = (bid % ntn) * BN;
+  if (m0 >= Mc) return;
+  const int HcWc = Hc * Wc, taps = p.kh * p.kw;
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.b), 0, 0x7fffffff, 0x00020000);
+  // A staging map as in conv_fwd32d_kernel; B: wave w, instruction i -> k-rows (w * 4 + i) * 2 + (lane >> 5), float4 column lane & 31
+  const int slot = lane & 7, lrow = lane >> 3;
+  int cy[4], cx[4];
+  unsigned abase[4], aq[4], voffA[4], voffB[4];
+  bool rv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (wave * 4 + i) * 8 + lrow;
+    const int m = m0 + row;
+    rv[i] = m < Mc;
+    const int mm = rv[i] ? m : 0;
+    const int n = mm / HcWc, rem = mm - n * HcWc;
+    const int a = rem / Wc, b = rem - a * Wc;
+    cy[i] = cy0 + a;
+    cx[i] = cx0 + b;
+    abase[i] = (unsigned)n * (unsigned)(p.Ho * p.Wo) * (unsigned)p.ycs * 4u;
+    aq[i] = (unsigned)(slot ^ ((row >> 1) & 7)) * 16u;
+    const int kr = (wave * 4 + i) * 2 + (lane >> 5);
+    const int csrc = ((lane & 31) * 4) ^ (((kr >> 2) & 3) << 4);          // source column of this LDS position
+    voffB[i] = n0 + csrc < p.Cin ? (unsigned)kr * (unsigned)(taps * p.wcs) * 4u + (unsigned)(n0 + csrc) * 4u : 0x80000000u;
+  }
+  auto locate = [&](int jy, int jx) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int oy = cy[i] - jy, ox = cx[i] - jx;
+      const bool v = rv[i] && (unsigned)oy < (unsigned)p.Ho && (unsigned)ox < (unsigned)p.Wo;
+      voffA[i] = v ? abase[i] + (unsigned)(oy * p.Wo + ox) * (unsigned)p.ycs * 4u + aq[i] : 0x80000000u;
+    }
+  };
+  int tj = 0, jy = 0, jx = 0, co = 0;       // walk state of the NEXT chunk to fetch (wave-uniform)
+  locate(0, 0);
+  auto issue = [&](int buf) {
+    const unsigned soA = (unsigned)co * 4u;
+    const unsigned soB = ((unsigned)co * (unsigned)taps + (unsigned)((py + jy * s) * p.kw + px + jx * s)) * (unsigned)p.wcs * 4u;
+    float* dA = sA + buf * BM * 32 + wave * 4 * 256;
+    float* dB = sB + buf * 32 * BN + wave * 4 * 256;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_t)(dA + i * 256), 16, voffA[i], soA, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_t)(dB + i * 256), 16, voffB[i], soB, 0, 0);
+    co += 32;
+    if (co >= p.c4) {
+      co = 0;
+      ++tj;
+      if (++jx == ntx) {
+        jx = 0;
+        ++jy;
+      }
+      if (tj < ntaps) locate(jy, jx);
+    }
+  };
+  const int lr = lane & 15, lq = lane >> 4;
+  f4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+  auto mma = [&](int buf) {
+    const float* A = sA + buf * BM * 32;
+    const float* B = sB + buf * 32 * BN;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      f4 fa[MT];
+      float fb[NT][4];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const f4*>(A + swz32(wm * MT * 16 + i * 16 + lr, lq + 4 * h));
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) fb[j][t] = B[(h * 16 + lq * 4 + t) * BN + ((wn * NT * 16 + j * 16 + lr) ^ (lq << 4))];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][t], fb[j][t], acc[i][j], 0, 0, 0);
+    }
+  };
+  const int nk = ntaps * (p.c4 >> 5);
+  if (nk > 0) {
+    issue(0);
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    for (int kc = 0; kc + 1 < nk; ++kc) {
+      const int buf = kc & 1;
+      issue(buf ^ 1);
+      mma(buf);
+      __builtin_amdgcn_s_waitcnt(0);
+      __syncthreads();
+    }
+    mma((nk - 1) & 1);
+  }
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      const int m = m0 + wm * MT * 16 + i * 16 + lq * 4 + rg;
+      if (m >= Mc) continue;
+      const int n = m / HcWc, rem = m - n * HcWc;
+      const int a = rem / Wc, b = rem - a * Wc;
+      float* orow = p.out + (((int64_t)n * p.Hin + (iyf + a * s)) * p.Win + (ixf + b * s)) * p.ocs;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int col = n0 + wn * NT * 16 + j * 16 + lr;
+        if (col < p.Cin) {
+          const float bias = p.bias ? p.bias[col] : 0.f;
+          orow[col] = cat::apply_act(acc[i][j][rg] + bias, p.act, p.slope);
+        } else if (col < p.cw) {
+          orow[col] = 0.f;
+        }
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ wgrad
 // rows = Cout (BM), cols = K = taps*cin4 (BN), reduction over the pixels [y*mchunk, (y+1)*mchunk).
 // (A 32-pixel-chunk variant of the 128 x 128 tile was measured 1.5 - 7 % SLOWER on every wide layer: this kernel is bound by the
@@ -1582,6 +1726,20 @@ static int conv_dgrad_impl(const cat_conv_t* g, const float* dy, const float* w,
   }
   // BK = 32 variant of the 128 x 128 tile (the discriminator's and the teacher's wide layers)
   static const int bk32 = getenv("CAT_DGRAD_BK32") ? atoi(getenv("CAT_DGRAD_BK32")) : 1;
+  static const int dgrad_direct = getenv("CAT_DGRAD_DIRECT") ? atoi(getenv("CAT_DGRAD_DIRECT")) : 1;
+  if (dgrad_direct && bk32 && a.ksplit == 1 && a.Cin > 96 && a.wvec && g->Cout % 32 == 0 && g->Cin % 4 == 0 && a.c4 == g->Cout &&
+      (int64_t)g->N * g->Ho * g->Wo * g->ycs * 4 < (int64_t)2147483647 && (int64_t)g->Cout * g->kh * g->kw * a.wcs * 4 < (int64_t)2147483647) {
+    cat::ProfScope prof("conv_dgrad32d_4x4x2x2", prof_flops, 0.0, stream);
+    const dim3 grid(cdiv(mmax, 128) * cdiv(a.Cin, 128), st * st);
+    const size_t lds = (size_t)2 * (128 + 128) * 32 * sizeof(float);
+    static bool attr_set_d = false;
+    if (!attr_set_d) {
+      (void)hipFuncSetAttribute((const void*)conv_dgrad32d_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr_set_d = true;
+    }
+    conv_dgrad32d_kernel<2><<<grid, 256, lds, s>>>(a);
+    return cat::check_launch("conv2d_dgrad");
+  }
   if (bk32 && a.ksplit == 1 && a.Cin > 96 && a.wvec && g->Cout % 16 == 0 && g->Cin % 4 == 0) {
     cat::ProfScope prof("conv_dgrad32_4x4x2x2", prof_flops, 0.0, stream);
     const dim3 grid(cdiv(mmax, 128) * cdiv(a.Cin, 128), st * st);
