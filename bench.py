@@ -350,18 +350,20 @@ def student_forward_rate(model, batch, spade, graph=True):
             'batch': int(x.shape[0])}
 
 
+PMC_FILE = 'profiles/r02_pmc_hbm.json'
+
+
 def pmc_traffic(family):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
-    (profiles/r01_e_pmc_hbm.json: FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled per the gfx950 note in
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command (PMC_FILE, written by
+    tools/profile_round.sh: FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled per the gfx950 note in
     MI355X_MICROARCH.md §HBM).  PMC collection cannot run inside the timed process, hence the lookup; None if absent."""
-    path = os.path.join(ROOT, 'profiles', 'r01_e_pmc_hbm.json')
+    path = os.path.join(ROOT, PMC_FILE)
     if not os.path.exists(path):
         return None
-    parts = family.split('_')                      # conv_fwd32_4x4x2x2 -> conv_fwd32_kernel<4, 4, 2, 2>
-    key = '_'.join(parts[:-1]) + '_kernel<' + ', '.join(parts[-1].split('x')) + '>'
+    base = family.rsplit('_', 1)[0]               # conv_fwd32d_4x4x2x2 -> conv_fwd32d
     table = json.load(open(path))
     for k, v in table.items():
-        if k.startswith(key[:-1]):
+        if k.startswith(base + '_kernel'):
             return v.get('hbm_bytes_per_launch')
     return None
 
@@ -408,6 +410,7 @@ def kernel_roofline(model, step, args):
     achieved = d['gflop_per_step'] / d['ms_per_step'] if d['ms_per_step'] > 0 else 0.0   # GFLOP/ms == TFLOP/s
     return {'bound': 'mfma', 'kernel': dom, 'achieved': round(achieved, 3), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
             'frac': round(achieved / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': pmc_traffic(dom) if (getattr(args, 'workload', 'c2') == 'c2' and args.size == 256 and args.batch == 16) else None,
+            'traffic_source': PMC_FILE + ' (separate rocprofv3 --pmc passes of this command; not a same-run measurement)',
             'avg_launch_us': round(1e3 * d['ms_per_step'] / max(d['launches_per_step'], 1), 3),
             'all_conv': {'achieved': round(tot_gf / tot_ms, 3) if tot_ms else 0.0, 'ms_per_step': round(tot_ms, 3),
                          'gflop_per_step': round(tot_gf, 2)},

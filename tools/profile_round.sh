@@ -15,6 +15,7 @@ fi
 # per-kernel durations are compared with bench.py's SERIAL roofline pass: branch streams off, no in-process event profiling
 export CAT_BRANCH_STREAMS=0
 B="python $PWD/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-profile --graph 0"
+SF="python $PWD/tools/debug/student_fwd_trace.py"
 (cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/prof_c2 -o bench -- $B > $OUT/prof_c2.log 2>&1)
 (cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/prof_spade -o bench -- $B --workload spade > $OUT/prof_spade.log 2>&1)
 if [ -z "$SKIP_PMC" ]; then
@@ -24,6 +25,15 @@ P="python $PWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-profi
 fi
 # summarise on the box; only the summaries travel back (gpurun returns <= 64 MiB)
 python tools/rocprof_summary.py $OUT/prof_c2/bench_results.db $OUT/kernel_stats_c2.txt 6 > /dev/null
+# the student forward alone (captured graph replays) and the SQ counters of the serial C2 command
+(cd /tmp && REPS=5 rocprofv3 --kernel-trace --stats -d $OUT/prof_sfwd -o sfwd -- $SF > $OUT/prof_sfwd.log 2>&1)
+python tools/rocprof_summary.py $OUT/prof_sfwd/sfwd_results.db $OUT/kernel_stats_student_fwd.txt 9 > /dev/null
+if [ -z "$SKIP_PMC" ]; then
+(cd /tmp && rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_WAVES --kernel-trace --output-format csv -d $OUT/pmc_sq -o q -- $P > $OUT/pmc_sq.log 2>&1)
+python tools/pmc_sq_summary.py $OUT/pmc_sq $OUT/pmc_sq_c2.txt > /dev/null 2>&1
+rm -rf $OUT/pmc_sq
+fi
+rm -rf $OUT/prof_sfwd
 python tools/rocprof_summary.py $OUT/prof_spade/bench_results.db $OUT/kernel_stats_spade.txt 6 > /dev/null
 [ -d $OUT/pmc ] && python tools/pmc_summary.py $OUT/pmc $OUT/pmc_hbm.json
 rm -rf $OUT/prof_c2 $OUT/prof_spade $OUT/pmc
