@@ -52,9 +52,19 @@ def _worker_inception(rank, world, port, q):
         A, B = detfill.images((n, 3, s, s), 810 + step), detfill.images((n, 3, s, s), 820 + step)
         model.set_input(parallel.shard_batch({'A': A, 'B': B, 'A_paths': [], 'B_paths': []}, rank, world))
         model.optimize_parameters(step)
-    model.finish_pending()
+    # a Trainer saves / evaluates right after optimize_parameters: the deferred student all-reduce + Adam step must be completed by
+    # save_networks itself (no explicit finish_pending here), and the checkpoint must hold the completed update
+    assert model._pending_G is not None
+    import tempfile
+    model.save_dir = tempfile.mkdtemp(prefix=f'cat_dp_{rank}_')
+    model.save_networks('dp')
+    assert model._pending_G is None
     torch.cuda.synchronize()
     keys = ['down_sampling.1.weight', 'features.4.res_ops.1.1.0.weight', 'up_sampling.7.weight']
+    saved = torch.load(os.path.join(model.save_dir, 'dp_net_G.pth'), map_location='cpu')
+    live = model.netG_student.state_dict()
+    for k in keys:
+        assert torch.equal(saved[k], live[k].detach().cpu()), k
     q.put((rank, {k: float(v) for k, v in model.get_current_losses().items()}, _probe(model.netG_student, keys),
            _probe(model.netD, ['model.0.weight', 'model.8.weight'])))
     torch.distributed.destroy_process_group()
