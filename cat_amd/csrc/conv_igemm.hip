@@ -1345,6 +1345,152 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(IgemmArgs p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------ wgrad, 32-pixel chunks, direct-to-LDS
+// dw[co][tap][ci] for the wide zero-padded layers (the PatchGAN's 4x4 convs, the teacher's stride-2 convs): 128 filters x 128 columns of
+// ONE tap per workgroup (Cin % 128 == 0), reduction over output pixels in chunks of 32 CONSECUTIVE PIXELS OF ONE OUTPUT ROW.  With that
+// chunk shape the source address of tile row r (pixel ox0 + r) is (row base) + (per-lane constant): the row base is an SGPR soffset,
+// so -- unlike conv_wgrad_kernel, whose (n, oy, ox) walk per 16-pixel chunk is what bounds it -- the steady state has no vector-ALU
+// address arithmetic; both tiles are DMA-ed into LDS (see conv_fwd32d_kernel).  Chunks whose input row falls into the zero padding are
+// skipped.  Tiles are [32 pixels][128] with the 16-column groups XOR-ed by (pixel >> 2) & 3 (applied to the source column), read with
+// ds_read_b32 like conv_wgrad_kernel.  blockIdx.y = slice of output rows; partial sums go to ws[slice][co][K] (or straight to dw).
+template <int WMW>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_wgrad32d_kernel(IgemmArgs p, int rows_per, int cpr) {
+  constexpr int MT = 4, NT = 4, WN = 2, BM = 128, BN = 128;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  typedef __attribute__((address_space(3))) void* lds_t;
+  float* sA = smem;                   // dy tile   [2][32][128]
+  float* sB = smem + 2 * 32 * BM;     // x  tile   [2][32][128]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int ntn = p.K / BN;
+  const int c0 = (blockIdx.x / ntn) * BM, k0 = (blockIdx.x % ntn) * BN;
+  const int tap = k0 / p.c4, ci0 = k0 - tap * p.c4;
+  const int ky = tap / p.kw, kx = tap - ky * p.kw;
+  const int R = p.N * p.Ho;
+  const int rbeg = blockIdx.y * rows_per, rend = min(R, rbeg + rows_per);
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.b), 0, 0x7fffffff, 0x00020000);   // dy
+  // x, with the base moved back by `pad` pixels: the scalar row offset below then never needs the (negative) "- pad" term, and the per-lane
+  // part stays non-negative; nothing is read in front of the tensor (those lanes are parked out of range)
+  const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a) - (int64_t)p.pad * p.xcs, 0, 0x7fffffff, 0x00020000);
+  // staging map: wave w, instruction i -> tile rows (w * 4 + i) * 2 + (lane >> 5), float4 column lane & 31
+  int trow[4];
+  unsigned colA[4], colB[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    trow[i] = (wave * 4 + i) * 2 + (lane >> 5);
+    const int csrc = ((lane & 31) * 4) ^ (((trow[i] >> 2) & 3) << 4);
+    colA[i] = c0 + csrc < ((p.Cout + 3) & ~3) ? (unsigned)(c0 + csrc) * 4u : 0x80000000u;
+    colB[i] = (unsigned)(ci0 + csrc) * 4u;
+  }
+  unsigned voffA[4], voffB[4];
+  auto locate = [&](int ox0) {        // per-lane offsets of one row segment (change only with the segment's start column)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int ox = ox0 + trow[i];
+      const int ix = ox * p.stride - p.pad + kx;
+      const bool pv = ox < p.Wo;
+      voffA[i] = (pv && colA[i] != 0x80000000u) ? (unsigned)trow[i] * (unsigned)p.ycs * 4u + colA[i] : 0x80000000u;
+      voffB[i] = (pv && (unsigned)ix < (unsigned)p.W) ? (unsigned)(trow[i] * p.stride + kx) * (unsigned)p.xcs * 4u + colB[i] : 0x80000000u;
+    }
+  };
+  // chunk cursor: (output row rr, segment sg); rows whose input row iy lies in the padding contribute nothing
+  int rr = rbeg, sg = 0;
+  auto valid_row = [&](int r) {
+    const int oy = r % p.Ho;
+    return (unsigned)(oy * p.stride - p.pad + ky) < (unsigned)p.H;
+  };
+  auto skip = [&]() {
+    while (rr < rend && !valid_row(rr)) ++rr;
+  };
+  skip();
+  int cur_sg = -1;
+  auto issue = [&](int buf) {
+    if (sg != cur_sg) {
+      locate(sg * 32);
+      cur_sg = sg;
+    }
+    const int n = rr / p.Ho, oy = rr - n * p.Ho;
+    const int iy = oy * p.stride - p.pad + ky;
+    const unsigned soA = (unsigned)((n * p.Ho + oy) * p.Wo + sg * 32) * (unsigned)p.ycs * 4u;
+    const unsigned soB = (unsigned)((n * p.H + iy) * p.W + sg * 32 * p.stride) * (unsigned)p.xcs * 4u;      // "- pad" lives in rB's base
+    float* dA = sA + buf * 32 * BM + wave * 4 * 256;
+    float* dB = sB + buf * 32 * BN + wave * 4 * 256;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_t)(dA + i * 256), 16, voffA[i], soA, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_t)(dB + i * 256), 16, voffB[i], soB, 0, 0);
+    if (++sg == cpr) {
+      sg = 0;
+      ++rr;
+      skip();
+    }
+  };
+  const int lr = lane & 15, lq = lane >> 4;
+  f4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+  auto mma = [&](int buf) {
+    const float* A = sA + buf * 32 * BM;
+    const float* B = sB + buf * 32 * BN;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      float fa[MT][4], fb[NT][4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int row = h * 16 + lq * 4 + t;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) fa[i][t] = A[row * BM + ((wm * MT * 16 + i * 16 + lr) ^ (lq << 4))];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) fb[j][t] = B[row * BN + ((wn * NT * 16 + j * 16 + lr) ^ (lq << 4))];
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][t], fb[j][t], acc[i][j], 0, 0, 0);
+    }
+  };
+  if (rr < rend) {
+    issue(0);
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    int buf = 0;
+    while (rr < rend) {
+      issue(buf ^ 1);
+      mma(buf);
+      __builtin_amdgcn_s_waitcnt(0);
+      __syncthreads();
+      buf ^= 1;
+    }
+    mma(buf);
+  }
+  const int taps = p.kh * p.kw;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int k = k0 + wn * NT * 16 + j * 16 + lr;
+    const int ci = k - tap * p.c4;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int co = c0 + wm * MT * 16 + i * 16 + lq * 4 + rg;
+        if (co >= p.Cout) continue;
+        if (p.direct) {
+          if (ci < p.cval) {
+            float* dst = p.out + ((int64_t)co * taps + tap) * p.wcs + ci;
+            *dst = p.accumulate ? *dst + acc[i][j][rg] : acc[i][j][rg];
+          }
+        } else {
+          p.out[((int64_t)blockIdx.y * p.Cout + co) * p.K + k] = acc[i][j][rg];
+        }
+      }
+    }
+  }
+}
+
 // dw[co][tap][ci] (+)= sum_z ws[z][co][tap*c4 + ci]; 64 outputs x 4 split-lanes per workgroup (coalesced in ci)
 // wlim = channels written per tap (Cin for dense storage, the padded extent otherwise), wcs = storage stride per tap
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nsplit,
@@ -1758,7 +1904,27 @@ static int conv_dgrad_impl(const cat_conv_t* g, const float* dy, const float* w,
   return cat::check_launch("conv2d_dgrad");
 }
 
+// direct-to-LDS wgrad (conv_wgrad32d_kernel): wide zero-padded layers whose 128-column K blocks lie inside one tap; returns the number
+// of output-row slices (0 = not applicable)
+static int wgrad32d_nsplit(const cat_conv_t* g, int* rows_per) {
+  static const int on = getenv("CAT_WGRAD_DIRECT") ? atoi(getenv("CAT_WGRAD_DIRECT")) : 1;
+  const int wcs = g->wcs > 0 ? g->wcs : g->Cin;
+  if (!on || g->Cout <= 96 || (g->Cin & 127) || g->pad_mode != CAT_PAD_ZERO || (g->Wo > 32 && (g->Wo & 31)) || cat::smallco_applicable(g) ||
+      (int64_t)g->N * g->H * g->W * g->xcs * 4 >= (int64_t)2147483647 || (int64_t)g->N * g->Ho * g->Wo * g->ycs * 4 >= (int64_t)2147483647 ||
+      wcs < g->Cin)
+    return 0;
+  const int tiles = cdiv(g->Cout, 128) * (g->kh * g->kw * g->Cin / 128);
+  const int R = g->N * g->Ho;
+  int ns = cdiv(1024, tiles);
+  if (ns > R) ns = R;
+  if (ns < 1) ns = 1;
+  const int rp = cdiv(R, ns);
+  if (rows_per) *rows_per = rp;
+  return cdiv(R, rp);
+}
+
 size_t cat_conv2d_wgrad_ws_bytes(const cat_conv_t* g) {
+  if (const int nsd = wgrad32d_nsplit(g, nullptr)) return (size_t)nsd * g->Cout * g->kh * g->kw * ((g->Cin + 3) & ~3) * sizeof(float);
   const WgradPlan pl = wgrad_plan(g);
   const size_t K = (size_t)g->kh * g->kw * ((g->Cin + 3) & ~3);
   if (cat::smallco_applicable(g)) return (size_t)cat::smallco_wgrad_nblk(g) * g->Cout * K * sizeof(float);
@@ -1791,6 +1957,32 @@ int cat_conv2d_wgrad(const cat_conv_t* g, const float* x, const float* dy, float
     return cat::check_launch("conv2d_wgrad_reduce");
   }
   const double prof_flops = 2.0 * (double)g->N * g->Ho * g->Wo * g->Cout * g->kh * g->kw * g->Cin;
+  int rows_per = 0;
+  if (const int nsd = wgrad32d_nsplit(g, &rows_per)) {
+    CAT_REQUIRE(nsd == 1 || ws != nullptr, "conv wgrad: workspace required");
+    a.nsplit = nsd;
+    a.direct = nsd == 1 ? 1 : 0;
+    a.out = a.direct ? dw : (float*)ws;
+    {
+      cat::ProfScope prof("conv_wgrad32d_4x4x2x2", prof_flops, 0.0, stream);
+      const dim3 grid(cdiv(a.Cout, 128) * (a.K / 128), nsd);
+      const size_t lds = (size_t)2 * 2 * 32 * 128 * sizeof(float);
+      static bool attr_set_w = false;
+      if (!attr_set_w) {
+        (void)hipFuncSetAttribute((const void*)conv_wgrad32d_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set_w = true;
+      }
+      conv_wgrad32d_kernel<2><<<grid, 256, lds, s>>>(a, rows_per, cdiv(g->Wo, 32));
+    }
+    if (int e = cat::check_launch("conv2d_wgrad")) return e;
+    if (!a.direct) {
+      const int64_t total = (int64_t)a.Cout * a.kh * a.kw * a.cval;
+      wgrad_reduce_kernel<<<(int)((total + 63) / 64), 256, 0, s>>>((const float*)ws, dw, nsd, a.Cout, a.kh * a.kw, a.cval, a.wcs, a.c4, a.K,
+                                                                    accumulate);
+      return cat::check_launch("conv2d_wgrad_reduce");
+    }
+    return 0;
+  }
   CAT_REQUIRE(a.direct || ws != nullptr, "conv wgrad: workspace required");
 #define LAUNCH(MT, NT, WM, WN)                                                                         \
   {                                                                                                    \

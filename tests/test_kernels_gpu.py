@@ -68,6 +68,11 @@ CONV_CASES = [
     (160, 112, 1, 1, 0, False, 0, 1, 5, 5),
     (256, 128, 4, 1, 1, False, 2, 3, 12, 10),
     (1024, 1, 4, 1, 1, False, 0, 4, 12, 12),
+    # direct-to-LDS forward / dgrad / wgrad tiles: Cin % 128 == 0, output rows of 64 and 40 -> 2 row segments, ragged last segment excluded;
+    # stride 1 with a 31-wide plane (the PatchGAN's 512 -> 1024 layer in small)
+    (128, 160, 4, 2, 1, False, 2, 1, 12, 128),
+    (256, 128, 4, 1, 1, False, 0, 2, 11, 32),
+    (128, 130, 3, 2, 1, False, 0, 2, 9, 64),
     (512, 1, 4, 1, 2, False, 0, 2, 9, 17),
 ]
 
