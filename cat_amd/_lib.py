@@ -84,6 +84,8 @@ SIGNATURES = {
     'cat_reflect_pad_bwd2': (c_i, [c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     'cat_affine_res_fwd': (c_i, [c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_p]),
     'cat_dwm_fwd': (c_i, [C.POINTER(DwmGeom), c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    'cat_dwm_bwd_ws_bytes': (C.c_size_t, [C.POINTER(DwmGeom)]),
+    'cat_dwm_bwd': (c_i, [C.POINTER(DwmGeom), c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_p]),
     'cat_prep_run': (c_i, [c_p, c_i, c_i, c_i, c_p]),
     'cat_dwconv2d_fwd': (c_i, [_G, c_p, c_p, c_p, c_p, c_p]),
     'cat_dwconv2d_dgrad': (c_i, [_G, c_p, c_p, c_p, c_i, c_p]),

@@ -399,3 +399,178 @@ extern "C" int cat_prep_run(const cat_prep_job_t* jobs_dev, int njobs, int total
   prep_kernel<<<total_blocks, 256, 0, (hipStream_t)stream>>>(jobs_dev, njobs, accumulate);
   return cat::check_launch("prep_run");
 }
+
+// ---------------------------------------------------------------------------------------------- depthwise stage, backward
+// Input gradient and filter gradient of ALL depthwise convs of a block in one launch (+ a small final reduction): replaces, per branch,
+// cat_dwconv2d_dgrad + the reflect fold + two slice copies + cat_dwconv2d_wgrad.  One workgroup = 8 x 16 pixels x all channel quads.
+//   dA[i]      = sum over the padded positions j that mirror onto i (j = i, and near a border -i / 2(H-1)-i) of
+//                sum_k dZ[j + p - k] * w[k]            (reflect padding; zero padding: j = i only, dZ = 0 outside the plane)
+//   dW[c][k]  += sum over the tile's output pixels o of dZ[o][c] * a[reflect(o - p + k)][c]     -> per-tile partials, reduced by
+//                dwm_wgrad_final_kernel straight into the parameters' gradient buffers
+namespace {
+
+struct DwmBwdArgs {
+  const float* a; const float* dz; const float* w; float* da; float* part;
+  int acs, zcs, dacs;
+  int N, H, W, nq, reflect;
+  int tiles_x, tiles;
+  int ks[CAT_DWM_MAXQ];
+};
+
+__global__ __launch_bounds__(256) void dwm_bwd_kernel(DwmBwdArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int TR = TH + 4, TC = TW + 4;
+  const int cs = p.nq * 4;
+  float* ta = smem;                       // [TR * TC][cs]   input activation patch (reflect- or zero-padded)
+  float* tz = ta + TR * TC * cs;          // [TR * TC][cs]   dZ patch (zero outside the plane)
+  float* sw = tz + TR * TC * cs;          // [25][cs]
+  const int tid = threadIdx.x;
+  const int tt = blockIdx.x, n = tt / p.tiles, t = tt - n * p.tiles;
+  const int oy0 = (t / p.tiles_x) * TH, ox0 = (t % p.tiles_x) * TW;
+  for (int i = tid; i < 25 * p.nq; i += 256) *reinterpret_cast<f4*>(sw + i * 4) = *reinterpret_cast<const f4*>(p.w + i * 4);
+  for (int i = tid; i < TR * TC * p.nq; i += 256) {
+    const int pix = i / p.nq, q = i - pix * p.nq;
+    const int r = pix / TC, c = pix - r * TC;
+    const int iy = oy0 - 2 + r, ix = ox0 - 2 + c;
+    const bool in = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+    f4 zv = {0.f, 0.f, 0.f, 0.f}, av = {0.f, 0.f, 0.f, 0.f};
+    if (in) zv = *reinterpret_cast<const f4*>(p.dz + (((int64_t)n * p.H + iy) * p.W + ix) * p.zcs + q * 4);
+    int ay = iy, ax = ix;
+    bool av_ok = in;
+    if (p.reflect) {
+      av_ok = iy > -p.H && iy < 2 * p.H - 1 && ix > -p.W && ix < 2 * p.W - 1;
+      ay = cat::reflect_idx(iy, p.H);
+      ax = cat::reflect_idx(ix, p.W);
+    }
+    if (av_ok) av = *reinterpret_cast<const f4*>(p.a + (((int64_t)n * p.H + ay) * p.W + ax) * p.acs + q * 4);
+    *reinterpret_cast<f4*>(tz + pix * cs + q * 4) = zv;
+    *reinterpret_cast<f4*>(ta + pix * cs + q * 4) = av;
+  }
+  __syncthreads();
+  // ---- input gradient: thread = (pixel, quad parity)
+  {
+    const int px = tid & 127, half = tid >> 7;
+    const int py = px >> 4, pxx = px & 15;
+    const int iy = oy0 + py, ix = ox0 + pxx;
+    if (iy < p.H && ix < p.W) {
+      // padded positions that mirror onto (iy, ix); zero padding: the pixel itself only
+      int ys[3], xs[3], ny = 0, nx = 0;
+      ys[ny++] = iy;
+      xs[nx++] = ix;
+      for (int q = half; q < p.nq; q += 2) {
+        const int ks = p.ks[q], pd = ks >> 1, o = 2 - pd;
+        ny = nx = 1;
+        if (p.reflect) {
+          if (iy >= 1 && iy <= pd) ys[ny++] = -iy;
+          if (iy <= p.H - 2 && iy >= p.H - 1 - pd) ys[ny++] = 2 * (p.H - 1) - iy;
+          if (ix >= 1 && ix <= pd) xs[nx++] = -ix;
+          if (ix <= p.W - 2 && ix >= p.W - 1 - pd) xs[nx++] = 2 * (p.W - 1) - ix;
+        }
+        f4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int a = 0; a < ny; ++a)
+          for (int b = 0; b < nx; ++b) {
+            const int jy = ys[a], jx = xs[b];
+            for (int ky = 0; ky < ks; ++ky) {
+              const int zy = jy + pd - ky - (oy0 - 2);          // row of dZ in the patch
+              if ((unsigned)zy >= (unsigned)TR) continue;
+              for (int kx = 0; kx < ks; ++kx) {
+                const int zx = jx + pd - kx - (ox0 - 2);
+                if ((unsigned)zx >= (unsigned)TC) continue;
+                acc += *reinterpret_cast<const f4*>(tz + (zy * TC + zx) * cs + q * 4) *
+                       *reinterpret_cast<const f4*>(sw + ((o + ky) * 5 + o + kx) * cs + q * 4);
+              }
+            }
+          }
+        *reinterpret_cast<f4*>(p.da + (((int64_t)n * p.H + iy) * p.W + ix) * p.dacs + q * 4) = acc;
+      }
+    }
+  }
+  // ---- filter gradient partials: work item = (tap of the 5 x 5 frame, quad), summed over the tile's 128 output pixels
+  float* part = p.part + (int64_t)tt * 25 * cs;
+  for (int wi = tid; wi < 25 * p.nq; wi += 256) {
+    const int tap = wi / p.nq, q = wi - tap * p.nq;
+    const int ks = p.ks[q], o = 2 - (ks >> 1);
+    const int fy = tap / 5, fx = tap - fy * 5;            // frame coordinates; the filter occupies [o, o + ks)
+    f4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (fy >= o && fy < o + ks && fx >= o && fx < o + ks) {
+      for (int py = 0; py < TH; ++py) {
+        if (oy0 + py >= p.H) break;
+        for (int pxx = 0; pxx < TW; ++pxx) {
+          if (ox0 + pxx >= p.W) break;
+          acc += *reinterpret_cast<const f4*>(tz + ((py + 2) * TC + pxx + 2) * cs + q * 4) *
+                 *reinterpret_cast<const f4*>(ta + ((py + fy) * TC + pxx + fx) * cs + q * 4);
+        }
+      }
+    }
+    *reinterpret_cast<f4*>(part + tap * cs + q * 4) = acc;
+  }
+}
+
+struct DwmFinArgs {
+  float* dst[CAT_TNORM_MAXSLICE];
+  int c0[CAT_TNORM_MAXSLICE], c[CAT_TNORM_MAXSLICE], ks[CAT_TNORM_MAXSLICE];
+  int nbr;
+};
+
+// dst_b[c][ky][kx] (+)= sum over tiles of part[tile][frame tap][c0_b + c]
+__global__ __launch_bounds__(256) void dwm_wgrad_final_kernel(const float* __restrict__ part, int ntiles, int cs, DwmFinArgs fa, int accumulate) {
+  const int b = blockIdx.y;
+  const int ks = fa.ks[b], taps = ks * ks, o = 2 - (ks >> 1);
+  const int e = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;      // one wave per (channel, tap)
+  if (e >= fa.c[b] * taps) return;
+  const int c = e / taps, tp = e - c * taps;
+  const int ky = tp / ks, kx = tp - ky * ks;
+  const float* src = part + ((o + ky) * 5 + o + kx) * cs + fa.c0[b] + c;
+  float s = 0.f;
+  for (int t = lane; t < ntiles; t += 64) s += src[(int64_t)t * 25 * cs];
+  s = cat::wave_sum(s);
+  if (lane == 0) fa.dst[b][e] = accumulate ? fa.dst[b][e] + s : s;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t cat_dwm_bwd_ws_bytes(const cat_dwm_t* g) {
+  return (size_t)g->N * cdiv(g->H, TH) * cdiv(g->W, TW) * 25 * g->nq * 4 * sizeof(float);
+}
+
+int cat_dwm_bwd(const cat_dwm_t* g, const float* a, const float* dz, const float* w25, float* da, int dacs, int nbranch, const int* c0,
+                const int* c, const int* ks, float* const* dw, int accumulate, void* ws, cat_stream_t stream) {
+  CAT_REQUIRE(g->nq >= 1 && g->nq <= CAT_DWM_MAXQ && nbranch >= 1 && nbranch <= CAT_TNORM_MAXSLICE && ws, "dwm bwd: bad arguments");
+  CAT_REQUIRE((g->xcs & 3) == 0 && (g->ycs & 3) == 0 && (dacs & 3) == 0 && g->xcs >= 4 * g->nq && g->ycs >= 4 * g->nq && dacs >= 4 * g->nq,
+              "dwm bwd: channel layout");
+  DwmBwdArgs p{};
+  p.a = a; p.dz = dz; p.w = w25; p.da = da; p.part = (float*)ws;
+  p.acs = g->xcs; p.zcs = g->ycs; p.dacs = dacs;
+  p.N = g->N; p.H = g->H; p.W = g->W; p.nq = g->nq; p.reflect = g->reflect;
+  p.tiles_x = cdiv(g->W, TW);
+  p.tiles = p.tiles_x * cdiv(g->H, TH);
+  double taps = 0.0;
+  for (int q = 0; q < g->nq; ++q) {
+    p.ks[q] = g->ks[q];
+    taps += 4.0 * g->ks[q] * g->ks[q];
+  }
+  const int cs = g->nq * 4, ntiles = g->N * p.tiles;
+  const size_t lds = (size_t)(2 * (TH + 4) * (TW + 4) * cs + 25 * cs) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)dwm_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    attr_set = true;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  cat::ProfScope prof("dwconv_bwd", 4.0 * (double)g->N * g->H * g->W * taps, 0.0, stream);
+  dwm_bwd_kernel<<<ntiles, 256, lds, s>>>(p);
+  if (int e = cat::check_launch("dwm_bwd")) return e;
+  DwmFinArgs fa{};
+  fa.nbr = nbranch;
+  int maxe = 0;
+  for (int b = 0; b < nbranch; ++b) {
+    fa.dst[b] = dw[b]; fa.c0[b] = c0[b]; fa.c[b] = c[b]; fa.ks[b] = ks[b];
+    maxe = c[b] * ks[b] * ks[b] > maxe ? c[b] * ks[b] * ks[b] : maxe;
+  }
+  dwm_wgrad_final_kernel<<<dim3(cdiv(maxe, 4), nbranch), 256, 0, s>>>((const float*)ws, ntiles, cs, fa, accumulate);
+  return cat::check_launch("dwm_wgrad_final");
+}
+
+}  // extern "C"

@@ -504,32 +504,43 @@ class _BlockFn(torch.autograd.Function):
                             p.gv['gd'] if p.affine else None, p.gv['bd'] if p.affine else None)
             if p.has_biasd:
                 _channel_sum(dzd, m_pix, p.hcd, p.hcd, p.gv['cd'])
+            # all depthwise convs at once: input gradient (reflect padding folded in the kernel) into the dw slices of dA1, filter gradients
+            # reduced straight into the parameters' gradient buffers
+            nb = len(p.dws)
+            gd = L.DwmGeom()
+            gd.N, gd.H, gd.W, gd.nq, gd.xcs, gd.ycs, gd.scs = n, h, w, p.hcd // 4, p.hc1, p.hcd, p.hcd
+            gd.reflect = int(p.reflect)
             for b in p.dws:
-                kd, m, w1 = b['kd'], b['m'], b['w1']
-                pd = (kd - 1) // 2
-                moded = pad_mode if pd > 0 else L.PAD_ZERO
-                dyp = C.c_void_p(dzd.data_ptr() + 4 * b['od'])
-                wc = b['dconv'].weight
-                gdw = ops._conv_geom(n, h, w, m, w1, h, w, m, p.hcd, kd, kd, 1, pd, moded)
-                hp, wp = (h + 2 * pd, w + 2 * pd) if moded == L.PAD_REFLECT else (h, w)
-                dxp = torch.empty((n, hp, wp, w1), device=dev, dtype=torch.float32)
-                L.call('cat_dwconv2d_dgrad', C.byref(gdw), dyp, ops._p(wc), ops._p(dxp), w1, st)
-                dsl = C.c_void_p(da1.data_ptr() + 4 * b['o1'])
-                # fold (pad 0 = plain strided copy) into this branch's slice of dA1
-                L.call('cat_reflect_pad_bwd2', ops._p(dxp), w1, dsl, p.hc1, None, 0, n, h, w, w1, pd if moded == L.PAD_REFLECT else 0, st)
-                # filter gradient: the kernel wants x and dy at one pixel stride -> compact copies of the two slices
-                xa = torch.empty((n, h, w, w1), device=dev, dtype=torch.float32)
-                dyc = torch.empty((n, h, w, w1), device=dev, dtype=torch.float32)
-                L.call('cat_slice_channels', ops._p(a1), p.hc1, b['o1'], w1, ops._p(xa), w1, m_pix, st)
-                L.call('cat_slice_channels', ops._p(dzd), p.hcd, b['od'], w1, ops._p(dyc), w1, m_pix, st)
-                gww = ops._conv_geom(n, h, w, m, w1, h, w, m, w1, kd, kd, 1, pd, moded)
-                keep += [xa, dyc]
-
-                def kdw(dst_, acc, sst, gww=gww, xa=xa, dyc=dyc):
-                    ws = ops.workspace(L.query('cat_dwconv2d_wgrad_ws_bytes', C.byref(gww)), dev)
-                    L.call('cat_dwconv2d_wgrad', C.byref(gww), ops._p(xa), ops._p(dyc), ops._p(dst_), acc, ops._p(ws), sst)
-                side.refork()
-                put_side(wc, kdw)
+                for q in range(b['od'] // 4, (b['od'] + _cs4(b['m'])) // 4):
+                    gd.ks[q] = b['kd']
+            wts = [b['dconv'].weight for b in p.dws]
+            tg = [ops._grad_target(q) for q in wts]
+            if all(t_ is not None for t_ in tg):
+                fresh = {q._cat_grad_state['fresh'] for q in wts}
+                if len(fresh) != 1:
+                    raise RuntimeError('fused block backward: depthwise gradient buffers out of sync')
+                acc_dw, dsts = (0 if fresh.pop() else 1), tg
+                for q in wts:
+                    q._cat_grad_state['fresh'] = False
+                    grads[id(q)] = None
+            else:
+                acc_dw, dsts = 0, [torch.empty_like(q) for q in wts]
+                for q, d_ in zip(wts, dsts):
+                    tq = ops._grad_target(q)
+                    if tq is None:
+                        grads[id(q)] = d_
+            IA = C.c_int * nb
+            wsd = ops.workspace(L.query('cat_dwm_bwd_ws_bytes', C.byref(gd)), dev)
+            L.call('cat_dwm_bwd', C.byref(gd), C.c_void_p(a1.data_ptr() + 4 * p.dw_in0), ops._p(dzd), ops._p(p.w25),
+                   C.c_void_p(da1.data_ptr() + 4 * p.dw_in0), p.hc1, nb, IA(*[b['od'] for b in p.dws]), IA(*[b['m'] for b in p.dws]),
+                   IA(*[b['kd'] for b in p.dws]), (C.c_void_p * nb)(*[d_.data_ptr() for d_ in dsts]), acc_dw, ops._p(wsd), st)
+            if not all(t_ is not None for t_ in tg):          # mixed ownership (tests): deliver into the owned views by hand
+                for q, d_ in zip(wts, dsts):
+                    tq = ops._grad_target(q)
+                    if tq is not None:
+                        (tq.copy_ if q._cat_grad_state['fresh'] else tq.add_)(d_)
+                        q._cat_grad_state['fresh'] = False
+                        grads[id(q)] = None
         # ---- 6. stage-1 norms (all branches at once)
         dz1 = _norm_bwd(p, n, hw, p.hc1, p.hc1, z1, da1, p.gamma1 if p.affine else None, p.beta1 if p.affine else None, mr1, p.act, p.slope,
                         p.gv['g1'] if p.affine else None, p.gv['b1'] if p.affine else None)

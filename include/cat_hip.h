@@ -328,6 +328,13 @@ typedef struct {
 } cat_dwm_t;
 int cat_dwm_fwd(const cat_dwm_t* g, const float* x, const float* scale, const float* shift, const float* w25, const float* bias, float* y,
                 float* stats, cat_stream_t stream);
+/* Backward of cat_dwm_fwd for all depthwise convs of a block: da (pixel stride dacs) = gradient w.r.t. the (activated) input slice `a`
+ * (pixel stride g->xcs), dz = gradient w.r.t. the pre-norm output (pixel stride g->ycs); reflect padding is folded in the kernel.  Filter
+ * gradients go to dw[b] ([c[b]][ks[b]][ks[b]], the parameters' own layout) for the nbranch branches whose channels are [c0[b], c0[b] + c[b])
+ * of the concatenation.  ws: cat_dwm_bwd_ws_bytes(g) bytes of scratch.  g->sstride / act / scs are ignored. */
+size_t cat_dwm_bwd_ws_bytes(const cat_dwm_t* g);
+int cat_dwm_bwd(const cat_dwm_t* g, const float* a, const float* dz, const float* w25, float* da, int dacs, int nbranch, const int* c0,
+                const int* c, const int* ks, float* const* dw, int accumulate, void* ws, cat_stream_t stream);
 /* Per-step preparation of a block's operands in ONE launch, driven by a job table resident in HBM (built once per network):
  *   kind 0  pack a conv weight for cat_tconv_fwd into columns [col0, col0 + Nn) of a stream with nt_total 16-wide N tiles (N-concatenated
  *           first convs; mode as cat_tconv_pack)
