@@ -69,6 +69,9 @@ SIGNATURES = {
     'cat_hip_version': (c_i, []),
     'cat_conv2d_fwd': (c_i, [_G, c_p, c_p, c_p, c_p, c_p]),
     'cat_conv2d_dgrad': (c_i, [_G, c_p, c_p, c_p, c_p, c_i, c_i, c_p]),
+    'cat_conv2d_dgrad_t_applicable': (c_i, [_G]),
+    'cat_conv2d_weight_transpose': (c_i, [_G, c_p, c_p, c_p]),
+    'cat_conv2d_dgrad_t': (c_i, [_G, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p]),
     'cat_conv2d_wgrad_ws_bytes': (C.c_size_t, [_G]),
     'cat_conv2d_fwd_ws_bytes': (C.c_size_t, [_G]),
     'cat_conv2d_fwd_ws': (c_i, [_G, c_p, c_p, c_p, c_p, c_p, c_p]),

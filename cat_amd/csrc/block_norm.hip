@@ -177,28 +177,42 @@ __global__ __launch_bounds__(256) void dwm_fwd_kernel(DwmArgs p) {
   const int g = p.sstride ? n : 0;       // per-image statistics (InstanceNorm) or one group
   for (int i = tid; i < 25 * p.nq; i += 256) *reinterpret_cast<f4*>(sw + i * 4) = *reinterpret_cast<const f4*>(p.w + i * 4);
   const float neg = p.act == CAT_ACT_RELU ? 0.f : (p.act == CAT_ACT_LRELU ? p.slope : 1.f);
-  for (int i = tid; i < TR * TC * p.nq; i += 256) {
-    const int pix = i / p.nq, q = i - pix * p.nq;
-    const int r = pix / TC, c = pix - r * TC;
-    int iy = oy0 - 2 + r, ix = ox0 - 2 + c;
-    bool v;
-    if (p.reflect) {
-      v = iy > -p.H && iy < 2 * p.H - 1 && ix > -p.W && ix < 2 * p.W - 1;
-      iy = cat::reflect_idx(iy, p.H);
-      ix = cat::reflect_idx(ix, p.W);
-    } else {
-      v = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-    }
-    f4 o = {0.f, 0.f, 0.f, 0.f};
-    if (v) {
-      const f4 xv = *reinterpret_cast<const f4*>(p.x + (((int64_t)n * p.H + iy) * p.W + ix) * p.xcs + q * 4);
-      const f4 sc = *reinterpret_cast<const f4*>(p.scale + g * p.sstride + q * 4);
-      const f4 sh = *reinterpret_cast<const f4*>(p.shift + g * p.sstride + q * 4);
-      o = xv * sc + sh;
+  constexpr int SIT = (TR * TC * CAT_DWM_MAXQ + 255) / 256;     // all of the thread's loads in flight before the first LDS store
+  f4 xv[SIT];
+  {
+    const f4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = o[e] > 0.f ? o[e] : o[e] * neg;
+    for (int it = 0; it < SIT; ++it) {
+      const int i = tid + it * 256;
+      xv[it] = zero;
+      if (i < TR * TC * p.nq) {
+        const int pix = i / p.nq, q = i - pix * p.nq;
+        const int r = pix / TC, c = pix - r * TC;
+        int iy = oy0 - 2 + r, ix = ox0 - 2 + c;
+        bool v;
+        if (p.reflect) {
+          v = iy > -p.H && iy < 2 * p.H - 1 && ix > -p.W && ix < 2 * p.W - 1;
+          iy = cat::reflect_idx(iy, p.H);
+          ix = cat::reflect_idx(ix, p.W);
+        } else {
+          v = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        }
+        if (v) {
+          const f4 x4 = *reinterpret_cast<const f4*>(p.x + (((int64_t)n * p.H + iy) * p.W + ix) * p.xcs + q * 4);
+          const f4 sc = *reinterpret_cast<const f4*>(p.scale + g * p.sstride + q * 4);
+          const f4 sh = *reinterpret_cast<const f4*>(p.shift + g * p.sstride + q * 4);
+          f4 o = x4 * sc + sh;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = o[e] > 0.f ? o[e] : o[e] * neg;
+          xv[it] = o;
+        }
+      }
     }
-    *reinterpret_cast<f4*>(tile + pix * cs + q * 4) = o;
+#pragma unroll
+    for (int it = 0; it < SIT; ++it) {
+      const int i = tid + it * 256;
+      if (i < TR * TC * p.nq) *reinterpret_cast<f4*>(tile + (i / p.nq) * cs + (i % p.nq) * 4) = xv[it];
+    }
   }
   __syncthreads();
   const int px = tid & 127, half = tid >> 7;
@@ -428,23 +442,38 @@ __global__ __launch_bounds__(256) void dwm_bwd_kernel(DwmBwdArgs p) {
   const int tt = blockIdx.x, n = tt / p.tiles, t = tt - n * p.tiles;
   const int oy0 = (t / p.tiles_x) * TH, ox0 = (t % p.tiles_x) * TW;
   for (int i = tid; i < 25 * p.nq; i += 256) *reinterpret_cast<f4*>(sw + i * 4) = *reinterpret_cast<const f4*>(p.w + i * 4);
-  for (int i = tid; i < TR * TC * p.nq; i += 256) {
-    const int pix = i / p.nq, q = i - pix * p.nq;
-    const int r = pix / TC, c = pix - r * TC;
-    const int iy = oy0 - 2 + r, ix = ox0 - 2 + c;
-    const bool in = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-    f4 zv = {0.f, 0.f, 0.f, 0.f}, av = {0.f, 0.f, 0.f, 0.f};
-    if (in) zv = *reinterpret_cast<const f4*>(p.dz + (((int64_t)n * p.H + iy) * p.W + ix) * p.zcs + q * 4);
-    int ay = iy, ax = ix;
-    bool av_ok = in;
-    if (p.reflect) {
-      av_ok = iy > -p.H && iy < 2 * p.H - 1 && ix > -p.W && ix < 2 * p.W - 1;
-      ay = cat::reflect_idx(iy, p.H);
-      ax = cat::reflect_idx(ix, p.W);
+  // staging in two phases (all global loads of the thread in flight, then the LDS stores): one workgroup per CU (89 KB of LDS), so
+  // nothing else would hide a load-store-load chain
+  constexpr int SIT = (TR * TC * CAT_DWM_MAXQ + 255) / 256;
+  f4 zv[SIT], av[SIT];
+#pragma unroll
+  for (int it = 0; it < SIT; ++it) {
+    const int i = tid + it * 256;
+    zv[it] = av[it] = f4{0.f, 0.f, 0.f, 0.f};
+    if (i < TR * TC * p.nq) {
+      const int pix = i / p.nq, q = i - pix * p.nq;
+      const int r = pix / TC, c = pix - r * TC;
+      const int iy = oy0 - 2 + r, ix = ox0 - 2 + c;
+      const bool in = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      if (in) zv[it] = *reinterpret_cast<const f4*>(p.dz + (((int64_t)n * p.H + iy) * p.W + ix) * p.zcs + q * 4);
+      int ay = iy, ax = ix;
+      bool av_ok = in;
+      if (p.reflect) {
+        av_ok = iy > -p.H && iy < 2 * p.H - 1 && ix > -p.W && ix < 2 * p.W - 1;
+        ay = cat::reflect_idx(iy, p.H);
+        ax = cat::reflect_idx(ix, p.W);
+      }
+      if (av_ok) av[it] = *reinterpret_cast<const f4*>(p.a + (((int64_t)n * p.H + ay) * p.W + ax) * p.acs + q * 4);
     }
-    if (av_ok) av = *reinterpret_cast<const f4*>(p.a + (((int64_t)n * p.H + ay) * p.W + ax) * p.acs + q * 4);
-    *reinterpret_cast<f4*>(tz + pix * cs + q * 4) = zv;
-    *reinterpret_cast<f4*>(ta + pix * cs + q * 4) = av;
+  }
+#pragma unroll
+  for (int it = 0; it < SIT; ++it) {
+    const int i = tid + it * 256;
+    if (i < TR * TC * p.nq) {
+      const int pix = i / p.nq, q = i - pix * p.nq;
+      *reinterpret_cast<f4*>(tz + pix * cs + q * 4) = zv[it];
+      *reinterpret_cast<f4*>(ta + pix * cs + q * 4) = av[it];
+    }
   }
   __syncthreads();
   // ---- input gradient: thread = (pixel, quad parity)

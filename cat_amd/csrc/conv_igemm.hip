@@ -46,6 +46,7 @@ struct IgemmArgs {
   // `kchunks` chunks; raw partial sums go to part[slice][pixel][channel], splitk_reduce_kernel adds bias / activation
   int ksplit, kchunks;
   float* part;
+  const float* bt;  // dgrad: filters transposed to [Cin][taps][Cout] (cat_conv2d_dgrad_t), or null
   int ablate;  // diagnostics only
   long long* dbg;  // diagnostics only (CAT_DBG): per-phase shader-clock totals of one wave
 };
@@ -1041,7 +1042,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // pre-swizzled); B = the filter slab [32 k][128 input channels], whose per-lane voffset NEVER changes: k = (class tap, filter co) only moves
 // the SGPR soffset (+32 filters per chunk, a new tap offset when co wraps).  The 16-column-group XOR of the N-contiguous tile is applied
 // to the source column each lane fetches.  Preconditions (host): Cout % 32 == 0, Cin % 4 == 0, float4-readable filters, tensors < 2 GB.
-template <int WMW>
+// BT: the filter operand comes from a copy transposed to [Cin][taps][Cout] (K-contiguous rows like the forward kernel's B tile: fragments
+// are read with ds_read_b128 instead of sixteen ds_read_b32 per half chunk); its voffsets are constant as well.
+template <bool BT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_dgrad32d_kernel(IgemmArgs p) {
   constexpr int MT = 4, NT = 4, WN = 2, BM = 128, BN = 128;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1064,8 +1067,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   if (m0 >= Mc) return;
   const int HcWc = Hc * Wc, taps = p.kh * p.kw;
   const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a), 0, 0x7fffffff, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.b), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(BT ? p.bt : p.b), 0, 0x7fffffff, 0x00020000);
   // A staging map as in conv_fwd32d_kernel; B: wave w, instruction i -> k-rows (w * 4 + i) * 2 + (lane >> 5), float4 column lane & 31
+  // (BT: rows = input channels, staged exactly like A)
   const int slot = lane & 7, lrow = lane >> 3;
   int cy[4], cx[4];
   unsigned abase[4], aq[4], voffA[4], voffB[4];
@@ -1082,9 +1086,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     cx[i] = cx0 + b;
     abase[i] = (unsigned)n * (unsigned)(p.Ho * p.Wo) * (unsigned)p.ycs * 4u;
     aq[i] = (unsigned)(slot ^ ((row >> 1) & 7)) * 16u;
-    const int kr = (wave * 4 + i) * 2 + (lane >> 5);
-    const int csrc = ((lane & 31) * 4) ^ (((kr >> 2) & 3) << 4);          // source column of this LDS position
-    voffB[i] = n0 + csrc < p.Cin ? (unsigned)kr * (unsigned)(taps * p.wcs) * 4u + (unsigned)(n0 + csrc) * 4u : 0x80000000u;
+    if (BT) {
+      const int cin = n0 + row;
+      voffB[i] = cin < p.Cin ? (unsigned)cin * (unsigned)(taps * p.Cout) * 4u + aq[i] : 0x80000000u;
+    } else {
+      const int kr = (wave * 4 + i) * 2 + (lane >> 5);
+      const int csrc = ((lane & 31) * 4) ^ (((kr >> 2) & 3) << 4);          // source column of this LDS position
+      voffB[i] = n0 + csrc < p.Cin ? (unsigned)kr * (unsigned)(taps * p.wcs) * 4u + (unsigned)(n0 + csrc) * 4u : 0x80000000u;
+    }
   }
   auto locate = [&](int jy, int jx) {
 #pragma unroll
@@ -1098,7 +1107,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   locate(0, 0);
   auto issue = [&](int buf) {
     const unsigned soA = (unsigned)co * 4u;
-    const unsigned soB = ((unsigned)co * (unsigned)taps + (unsigned)((py + jy * s) * p.kw + px + jx * s)) * (unsigned)p.wcs * 4u;
+    const unsigned tapi = (unsigned)((py + jy * s) * p.kw + px + jx * s);
+    const unsigned soB = BT ? (tapi * (unsigned)p.Cout + (unsigned)co) * 4u : ((unsigned)co * (unsigned)taps + tapi) * (unsigned)p.wcs * 4u;
     float* dA = sA + buf * BM * 32 + wave * 4 * 256;
     float* dB = sB + buf * 32 * BN + wave * 4 * 256;
 #pragma unroll
@@ -1132,9 +1142,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
       for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const f4*>(A + swz32(wm * MT * 16 + i * 16 + lr, lq + 4 * h));
 #pragma unroll
-      for (int j = 0; j < NT; ++j)
+      for (int j = 0; j < NT; ++j) {
+        if (BT) {
+          const f4 v = *reinterpret_cast<const f4*>(B + swz32(wn * NT * 16 + j * 16 + lr, lq + 4 * h));
 #pragma unroll
-        for (int t = 0; t < 4; ++t) fb[j][t] = B[(h * 16 + lq * 4 + t) * BN + ((wn * NT * 16 + j * 16 + lr) ^ (lq << 4))];
+          for (int t = 0; t < 4; ++t) fb[j][t] = v[t];
+        } else {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) fb[j][t] = B[(h * 16 + lq * 4 + t) * BN + ((wn * NT * 16 + j * 16 + lr) ^ (lq << 4))];
+        }
+      }
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -1491,6 +1508,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
 }
 
+// wt[ci][tap][co] = w[co][tap][ci]: 32 x 32 tiles through LDS, one (tap, tile) per workgroup
+__global__ __launch_bounds__(256) void weight_transpose_kernel(const float* __restrict__ w, float* __restrict__ wt, int Cout, int Cin, int taps,
+                                                               int wcs) {
+  __shared__ float tile[32][33];
+  const int tap = blockIdx.z, co0 = blockIdx.y * 32, ci0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) {
+    const int co = co0 + r, ci = ci0 + tx;
+    tile[r][tx] = (co < Cout && ci < Cin) ? w[((int64_t)co * taps + tap) * wcs + ci] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int ci = ci0 + r, co = co0 + tx;
+    if (ci < Cin && co < Cout) wt[((int64_t)ci * taps + tap) * Cout + co] = tile[tx][r];
+  }
+}
+
 // dw[co][tap][ci] (+)= sum_z ws[z][co][tap*c4 + ci]; 64 outputs x 4 split-lanes per workgroup (coalesced in ci)
 // wlim = channels written per tap (Cin for dense storage, the padded extent otherwise), wcs = storage stride per tap
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nsplit,
@@ -1822,24 +1856,50 @@ size_t cat_conv2d_dgrad_ws_bytes(const cat_conv_t* g, int dxcs) {
   return (size_t)sp.ksplit * g->N * Hin * Win * dxcs * sizeof(float);
 }
 
-static int conv_dgrad_impl(const cat_conv_t* g, const float* dy, const float* w, const float* bias, float* dx, int dxcs, int dxcw, void* ws,
-                           cat_stream_t stream);
+static int conv_dgrad_impl(const cat_conv_t* g, const float* dy, const float* w, const float* wt, const float* bias, float* dx, int dxcs, int dxcw,
+                           void* ws, cat_stream_t stream);
 
 int cat_conv2d_dgrad(const cat_conv_t* g, const float* dy, const float* w, const float* bias, float* dx, int dxcs, int dxcw,
                      cat_stream_t stream) {
-  return conv_dgrad_impl(g, dy, w, bias, dx, dxcs, dxcw, nullptr, stream);
+  return conv_dgrad_impl(g, dy, w, nullptr, bias, dx, dxcs, dxcw, nullptr, stream);
 }
 
 int cat_conv2d_dgrad_ws(const cat_conv_t* g, const float* dy, const float* w, const float* bias, float* dx, int dxcs, int dxcw, void* ws,
                         cat_stream_t stream) {
-  return conv_dgrad_impl(g, dy, w, bias, dx, dxcs, dxcw, ws, stream);
+  return conv_dgrad_impl(g, dy, w, nullptr, bias, dx, dxcs, dxcw, ws, stream);
 }
 
-static int conv_dgrad_impl(const cat_conv_t* g, const float* dy, const float* w, const float* bias, float* dx, int dxcs, int dxcw, void* ws,
-                           cat_stream_t stream) {
+// does the direct-to-LDS dgrad tile apply (and with it the transposed-filter variant)?
+static bool dgrad32d_ok(const cat_conv_t* g) {
+  static const int on = getenv("CAT_DGRAD_DIRECT") ? atoi(getenv("CAT_DGRAD_DIRECT")) : 1;
+  const int wcs = g->wcs > 0 ? g->wcs : g->Cin;
+  return on && g->Cin > 96 && (wcs & 3) == 0 && g->Cout % 32 == 0 && g->Cin % 4 == 0 &&
+         (int64_t)g->N * g->Ho * g->Wo * g->ycs * 4 < (int64_t)2147483647 && (int64_t)g->Cout * g->kh * g->kw * wcs * 4 < (int64_t)2147483647;
+}
+
+int cat_conv2d_dgrad_t_applicable(const cat_conv_t* g) {
+  static const int on = getenv("CAT_DGRAD_T") ? atoi(getenv("CAT_DGRAD_T")) : 1;
+  return on && dgrad32d_ok(g) && g->stride >= 1 && dgrad_split(g).ksplit <= 1 ? 1 : 0;
+}
+
+int cat_conv2d_weight_transpose(const cat_conv_t* g, const float* w, float* wt, cat_stream_t stream) {
+  const int wcs = g->wcs > 0 ? g->wcs : g->Cin;
+  CAT_REQUIRE(g->Cin > 0 && g->Cout > 0 && wcs >= g->Cin, "weight transpose: bad geometry");
+  const dim3 grid(cdiv(g->Cin, 32), cdiv(g->Cout, 32), g->kh * g->kw);
+  weight_transpose_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(w, wt, g->Cout, g->Cin, g->kh * g->kw, wcs);
+  return cat::check_launch("weight_transpose");
+}
+
+int cat_conv2d_dgrad_t(const cat_conv_t* g, const float* dy, const float* w, const float* wt, const float* bias, float* dx, int dxcs, int dxcw,
+                       cat_stream_t stream) {
+  return conv_dgrad_impl(g, dy, w, wt, bias, dx, dxcs, dxcw, nullptr, stream);
+}
+
+static int conv_dgrad_impl(const cat_conv_t* g, const float* dy, const float* w, const float* wt, const float* bias, float* dx, int dxcs, int dxcw,
+                           void* ws, cat_stream_t stream) {
   IgemmArgs a{};
   if (int e = fill_common(a, g)) return e;
-  a.a = dy; a.b = w; a.bias = bias; a.out = dx;
+  a.a = dy; a.b = w; a.bt = wt; a.bias = bias; a.out = dx;
   a.cval = (g->Cout + 3) & ~3;
   a.c4 = walk_extent(a.cval);
   a.cw = dxcw > g->Cin ? dxcw : g->Cin;
@@ -1872,18 +1932,18 @@ static int conv_dgrad_impl(const cat_conv_t* g, const float* dy, const float* w,
   }
   // BK = 32 variant of the 128 x 128 tile (the discriminator's and the teacher's wide layers)
   static const int bk32 = getenv("CAT_DGRAD_BK32") ? atoi(getenv("CAT_DGRAD_BK32")) : 1;
-  static const int dgrad_direct = getenv("CAT_DGRAD_DIRECT") ? atoi(getenv("CAT_DGRAD_DIRECT")) : 1;
-  if (dgrad_direct && bk32 && a.ksplit == 1 && a.Cin > 96 && a.wvec && g->Cout % 32 == 0 && g->Cin % 4 == 0 && a.c4 == g->Cout &&
-      (int64_t)g->N * g->Ho * g->Wo * g->ycs * 4 < (int64_t)2147483647 && (int64_t)g->Cout * g->kh * g->kw * a.wcs * 4 < (int64_t)2147483647) {
-    cat::ProfScope prof("conv_dgrad32d_4x4x2x2", prof_flops, 0.0, stream);
+  if (bk32 && a.ksplit == 1 && dgrad32d_ok(g) && a.c4 == g->Cout) {
+    cat::ProfScope prof(wt ? "conv_dgrad32dt_4x4x2x2" : "conv_dgrad32d_4x4x2x2", prof_flops, 0.0, stream);
     const dim3 grid(cdiv(mmax, 128) * cdiv(a.Cin, 128), st * st);
     const size_t lds = (size_t)2 * (128 + 128) * 32 * sizeof(float);
     static bool attr_set_d = false;
     if (!attr_set_d) {
-      (void)hipFuncSetAttribute((const void*)conv_dgrad32d_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute((const void*)conv_dgrad32d_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute((const void*)conv_dgrad32d_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       attr_set_d = true;
     }
-    conv_dgrad32d_kernel<2><<<grid, 256, lds, s>>>(a);
+    if (wt) conv_dgrad32d_kernel<true><<<grid, 256, lds, s>>>(a);
+    else conv_dgrad32d_kernel<false><<<grid, 256, lds, s>>>(a);
     return cat::check_launch("conv2d_dgrad");
   }
   if (bk32 && a.ksplit == 1 && a.Cin > 96 && a.wvec && g->Cout % 16 == 0 && g->Cin % 4 == 0) {

@@ -356,7 +356,29 @@ def _conv_fwd(g, x, w, bias, y, st):
         L.call('cat_conv2d_fwd', C.byref(g), _p(x), _p(w), _p(bias), _p(y), st)
 
 
-def _conv_dgrad(g, dy, w, bias, dx, dxcs, dxcw, st):
+def transposed_filter(weight, wcl, g):
+    """[Cin][kh][kw][Cout] copy of a conv weight for cat_conv2d_dgrad_t, cached on the tensor and refreshed when the weight changed (same
+    keying as packed_filter: version counter, or the optimizer epoch for FusedAdam-owned parameters)."""
+    from . import optim
+    owner = weight if weight is not None else wcl
+    trainable = getattr(owner, '_cat_grad_view', None) is not None
+    key = (wcl.data_ptr(), wcl._version, optim.weights_epoch() if trainable else -1)
+    ent = getattr(owner, '_cat_wt', None)
+    if ent is not None and ent[0] == key:
+        return ent[1]
+    o, i, kh, kw = wcl.shape
+    buf = ent[1] if (ent is not None and ent[1].numel() == o * i * kh * kw and ent[1].device == wcl.device) else \
+        torch.empty(o * i * kh * kw, device=wcl.device, dtype=torch.float32)
+    L.call('cat_conv2d_weight_transpose', C.byref(g), _p(wcl), _p(buf), _stream())
+    owner._cat_wt = (key, buf)
+    return buf
+
+
+def _conv_dgrad(g, dy, w, bias, dx, dxcs, dxcw, st, weight=None):
+    if L.query('cat_conv2d_dgrad_t_applicable', C.byref(g)) and weight_wcs(w) is not None:
+        wt = transposed_filter(weight, w, g)
+        L.call('cat_conv2d_dgrad_t', C.byref(g), _p(dy), _p(w), _p(wt), _p(bias), _p(dx), dxcs, dxcw, st)
+        return
     nb = L.query('cat_conv2d_dgrad_ws_bytes', C.byref(g), dxcs)
     if nb:
         L.call('cat_conv2d_dgrad_ws', C.byref(g), _p(dy), _p(w), _p(bias), _p(dx), dxcs, dxcw, _p(workspace(nb, dx.device)), st)
@@ -412,7 +434,7 @@ class Conv2dFn(torch.autograd.Function):
                 if tile:   # gradient of the PADDED plane: full correlation of dy with the flipped filters
                     tconv.run([tconv.Segment(dy, kh, kh - 1, False, 0)], pk, None, dxp, cin, n, ho, wo, h + 2 * pad, w + 2 * pad)
                 else:
-                    _conv_dgrad(g, dy, wcl, None, dxp, act_cs(dxp), act_cs(dxp), st)
+                    _conv_dgrad(g, dy, wcl, None, dxp, act_cs(dxp), act_cs(dxp), st, ctx.weight)
                 dx = empty_act(n, cin, h, w, x.device)
                 L.call('cat_reflect_pad_bwd', _p(dxp), _p(dx), n, h, w, cin, act_cs(dx), pad, st)
             else:
@@ -420,7 +442,7 @@ class Conv2dFn(torch.autograd.Function):
                 if tile:
                     tconv.run([tconv.Segment(dy, kh, kh - 1 - pad, False, 0)], pk, None, dx, cin, n, ho, wo, h, w)
                 else:
-                    _conv_dgrad(g, dy, wcl, None, dx, act_cs(dx), act_cs(dx), st)
+                    _conv_dgrad(g, dy, wcl, None, dx, act_cs(dx), act_cs(dx), st, ctx.weight)
         if ctx.needs_input_grad[1]:
             ws = workspace(L.query('cat_conv2d_wgrad_ws_bytes', C.byref(g)), x.device)
 

@@ -54,6 +54,14 @@ int cat_conv2d_fwd(const cat_conv_t* g, const float* x, const float* w, const fl
  * dxcw: channels [Cin, dxcw) of dx are zeroed. */
 int cat_conv2d_dgrad(const cat_conv_t* g, const float* dy, const float* w, const float* bias, float* dx,
                      int dxcs, int dxcw, cat_stream_t stream);
+/* Input gradient with a TRANSPOSED copy of the filters, wt = [Cin][kh][kw][Cout] (cat_conv2d_weight_transpose, refreshed whenever the
+ * weights change: once per optimizer step for a trainable layer): both MFMA operands of the wide 128 x 128 x 32 tile are then K-contiguous
+ * in LDS, like the forward kernel's.  cat_conv2d_dgrad_t_applicable says whether the layer takes that path; otherwise (or with wt = NULL)
+ * the call is cat_conv2d_dgrad. */
+int cat_conv2d_dgrad_t_applicable(const cat_conv_t* g);
+int cat_conv2d_weight_transpose(const cat_conv_t* g, const float* w, float* wt, cat_stream_t stream);
+int cat_conv2d_dgrad_t(const cat_conv_t* g, const float* dy, const float* w, const float* wt, const float* bias, float* dx, int dxcs,
+                       int dxcw, cat_stream_t stream);
 /* dw[Cout][kh][kw][Cin] (+)= sum_pixels dy * im2col(x).  `ws` is scratch of cat_conv2d_wgrad_ws_bytes(g) bytes.
  * accumulate != 0 adds into dw (gradient accumulation over several backward calls). */
 size_t cat_conv2d_wgrad_ws_bytes(const cat_conv_t* g);
