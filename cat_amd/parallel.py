@@ -98,6 +98,7 @@ class DataParallelReducer:
                     dist.broadcast(stage, src=src, group=self.group)
                     d.copy_(stage)
                 t.__dict__.pop('_cat_pk', None)        # packed-filter cache of the LDS-tile convs
+                t.__dict__.pop('_cat_wt', None)        # transposed-filter cache of the wide dgrad tiles
             # the broadcast wrote through .data (no version bump): drop every cache derived from the old values
             for sub in m.modules():
                 for attr in ('_cat_frozen', '_cat_fold', '_cat_fused_plan'):
