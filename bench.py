@@ -175,7 +175,10 @@ def main():
                '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
         raise SystemExit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))))
     # stdout carries exactly ONE line, the JSON record: everything the build prints (pruning search log, ...) goes to stderr
-    json_out = sys.stdout
+    # (also at the file-descriptor level: RCCL / gloo / HIP runtime messages are written by native code straight to fd 1)
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), 'w')
+    os.dup2(2, 1)
     sys.stdout = sys.stderr
     spade = args.workload == 'spade'
     if args.batch is None:
