@@ -165,3 +165,45 @@ def test_evaluate_model_on_gpu(c2, tmp_path):
     ref, _ = ref_cpu.inception_generator(_cpu(model.netG_student), batches[1]['A'], ncfg, training=False)
     assert H.rel_err(seen['fakes'][1].numpy(), ref.numpy()) < 1e-3
     assert os.path.exists(os.path.join(str(tmp_path), 'eval', '7', 'Sfake', '1_b.png'))
+
+
+@pytest.mark.timeout(900)
+def test_spade_step_at_512x256_matches_oracle(capsys):
+    """BASELINE configs[3] at its real size: the bench's own GauGAN model (teacher ngf 64, student ngf 48 pruned to 5.6e9 MACs, multiscale
+    SN-PatchGAN ndf 64, VGG feature loss, KA) -- one SPADEDistiller.optimize_parameters at 512 x 256, batch 1, against
+    oracle/ref_spade_cpu.spade_step on the same weights / labels / image (~30-60 s of host work)."""
+    import bench
+    from cat_amd import _lib, ops
+    from oracle import ref_spade_cpu as R
+    _lib.load()
+    old = ops.set_tconv_min_tiles(1)
+    try:
+        args = argparse.Namespace(workload='spade', batch=1, size=256, target_flops=5.6e9)
+        model, opt = bench.build_spade_model(args, 0)
+        m = model.modules_on_one_gpu
+        vsd = {k.split('.', 1)[1]: v for k, v in _cpu(m.criterionVGG.vgg).items()}
+        cfg = dict(G=dict(crop_size=opt.crop_size, aspect_ratio=opt.aspect_ratio, num_upsampling_layers=opt.num_upsampling_layers), num_D=2,
+                   n_layers_D=4, lambda_gan=1.0, lambda_feat=10.0, lambda_vgg=10.0, lambda_distill=0.5, lr=opt.lr, beta1=0.5, beta2=0.999,
+                   no_TTUR=False)
+        st = R.SpadeState(_cpu(m.netG_teacher), _cpu(m.netG_student), _cpu(m.netD), vsd, cfg)
+        h, w = 256, 512
+        rng = np.random.default_rng(5)
+        lab = torch.from_numpy(np.repeat(np.repeat(rng.integers(0, 35, (1, 1, h // 16, w // 16)), 16, 2), 16, 3))
+        ins = torch.from_numpy(np.repeat(np.repeat(rng.integers(0, 1000, (1, 1, h // 16, w // 16)), 16, 2), 16, 3).astype(np.int32))
+        img = detfill.images((1, 3, h, w), 6)
+        R.spade_step(st, R.preprocess_input(lab, ins, 35), img)
+        ops.STATS['conform_copies'] = 0
+        model.set_input({'label': lab.cuda(), 'instance': ins.cuda(), 'image': img.cuda(), 'path': []})
+        model.optimize_parameters(0)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_tconv_min_tiles(old)
+    got = {k.split('/')[-1]: v for k, v in model.get_current_losses().items()}
+    report = {k: abs(got[k] - v) / max(abs(v), 1e-2) for k, v in st.losses.items() if k in got}
+    report['Sfake_B'] = H.rel_err(model.Sfake_B.detach().cpu().numpy(), st.Sfake_B.numpy())
+    report['Tfake_B'] = H.rel_err(model.Tfake_B.detach().cpu().numpy(), st.Tfake_B.numpy())
+    with capsys.disabled():
+        print('\n[headline parity SPADE @512x256, batch 1] max relative deviation from the CPU oracle: ' + json.dumps({k: float('%.3g' % v) for k, v in report.items()}))
+    assert ops.STATS['conform_copies'] == 0
+    for k, v in report.items():
+        assert v < 2e-3, (k, v)
