@@ -190,6 +190,8 @@ __device__ __forceinline__ float loss_term(int kind, float a, float b, float t) 
     case 2: return -fminf(a - 1.f, 0.f);
     case 3: return -fminf(-a - 1.f, 0.f);
     case 4: return -a;
+    case 6: return (1.f - t) * a + fmaxf(-a, 0.f) + log1pf(expf(-fabsf(a)));   // BCE with logits against the constant target t
+    case 7: return a;
     default: return (a - b) * (a - b);
   }
 }
@@ -200,6 +202,8 @@ __device__ __forceinline__ float loss_grad(int kind, float a, float b, float t) 
     case 2: return a - 1.f < 0.f ? -1.f : 0.f;   // torch.min(x-1, 0): ties send the gradient to ... see tests (measure zero)
     case 3: return -a - 1.f < 0.f ? 1.f : 0.f;
     case 4: return -1.f;
+    case 6: return 1.f / (1.f + expf(-a)) - t;   // sigmoid(a) - t
+    case 7: return 1.f;
     default: return 2.f * (a - b);
   }
 }
@@ -290,7 +294,7 @@ size_t cat_loss_ws_bytes(int64_t M) { (void)M; return 1024 * sizeof(float); }
 
 int cat_loss_fwd(int kind, const float* a, const float* b, float target, int64_t M, int C, int cs, float* out, void* ws,
                  cat_stream_t stream) {
-  CAT_REQUIRE(kind >= 0 && kind <= 5 && cs % 4 == 0 && cs >= C && ws, "loss: bad arguments");
+  CAT_REQUIRE(kind >= 0 && kind <= 7 && cs % 4 == 0 && cs >= C && ws, "loss: bad arguments");
   CAT_REQUIRE((kind != 0 && kind != 5) || b, "loss: kind %d needs a second tensor", kind);
   const int64_t nquads = M * (cs / 4);
   const int nb = loss_nb(nquads);
@@ -303,7 +307,7 @@ int cat_loss_fwd(int kind, const float* a, const float* b, float target, int64_t
 
 int cat_loss_bwd(int kind, const float* a, const float* b, float target, int64_t M, int C, int cs, const float* gout, float scale,
                  float* da, cat_stream_t stream) {
-  CAT_REQUIRE(kind >= 0 && kind <= 5 && cs % 4 == 0 && cs >= C, "loss: bad arguments");
+  CAT_REQUIRE(kind >= 0 && kind <= 7 && cs % 4 == 0 && cs >= C, "loss: bad arguments");
   const int64_t nquads = M * (cs / 4);
   int64_t nb = (nquads + 255) / 256;
   if (nb > 8192) nb = 8192;

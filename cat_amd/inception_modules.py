@@ -224,7 +224,7 @@ class ConvSyncBNReLU(nn.Module):
         return self.active(y, applied=True)
 
     def remove_spectral_norm(self):
-        raise NotImplementedError('remove_spectral_norm belongs to the export path (out of scope)')
+        self.conv = cnn.remove_spectral_norm(self.conv)
 
 
 class Conv(nn.Module):
@@ -238,6 +238,9 @@ class Conv(nn.Module):
 
     def forward(self, x):
         return self.conv(x)
+
+    def remove_spectral_norm(self):
+        self.conv = cnn.remove_spectral_norm(self.conv)
 
 
 def _run_branches(branch_ops, x, extra=()):
@@ -474,7 +477,15 @@ class SPADEInvertedResidualChannels(nn.Module):
         return _run_branches(branch_ops, tmp, extra=(self._shortcut(x_short),))
 
     def remove_spectral_norm(self):
-        raise NotImplementedError('remove_spectral_norm belongs to the export path (out of scope)')
+        """Reference inception_modules.py:571-586 (export path): every conv of every branch and of the learned shortcut gets its
+        normalised weight baked in; a conv that carries no spectral norm raises ValueError, as torch's remove_spectral_norm does."""
+        carriers = [m for op in list(self.res_ops) + list(self.dw_ops) for m in op]
+        if self.shortcut is not None:
+            carriers.append(self.shortcut[1])
+        for m in carriers:
+            if not isinstance(m, (ConvSyncBNReLU, Conv)):
+                raise TypeError('unexpected module in a SPADE branch: %s' % type(m).__name__)
+            m.remove_spectral_norm()
 
     def __repr__(self):
         return ('{}({}, {}, res_channels={}, dw_channels={}, res_kernel_sizes={}, dw_kernel_sizes={})\n\tSPADE: {}').format(

@@ -77,7 +77,12 @@ class InceptionSPADEGenerator(BaseNetwork):
         return (x, ret_acts) if len(mapping_layers) else x
 
     def remove_spectral_norm(self):
-        raise NotImplementedError('remove_spectral_norm belongs to the export path (out of scope)')
+        """Reference inception_spade_generator.py:126-137 (export path)."""
+        names = ['head_0', 'G_middle_0', 'G_middle_1', 'up_0', 'up_1', 'up_2', 'up_3']
+        if self.opt.num_upsampling_layers == 'most':
+            names.append('up_4')
+        for name in names:
+            getattr(self, name).remove_spectral_norm()
 
     def get_named_block_list(self):
         return _get_named_block_list(self, spade=True, num_upsampling_layers=self.opt.num_upsampling_layers)

@@ -1,4 +1,4 @@
-"""Losses of the distillation step: GANLoss (reference models/modules/loss.py:8-99, hinge + lsgan), the L1 / MSE
+"""Losses of the distillation step: GANLoss (reference models/modules/loss.py:8-99: hinge, lsgan, vanilla, wgangp), the L1 / MSE
 reconstruction criteria and KA (utils/common.py:38-46).  Each evaluates to a 0-d device tensor produced (and
 differentiated) by the reduction kernels of libcat_hip.so."""
 from torch import nn
@@ -12,7 +12,7 @@ class GANLoss(nn.Module):
         super(GANLoss, self).__init__()
         self.real_label = float(target_real_label)
         self.fake_label = float(target_fake_label)
-        if gan_mode not in ('lsgan', 'hinge'):
+        if gan_mode not in ('lsgan', 'hinge', 'vanilla', 'wgangp'):
             raise NotImplementedError('gan mode %s not implemented' % gan_mode)
         self.gan_mode = gan_mode
 
@@ -20,6 +20,11 @@ class GANLoss(nn.Module):
         if self.gan_mode == 'lsgan':
             target = self.real_label if target_is_real else self.fake_label
             return ops.LossFn.apply(prediction, None, L.LOSS_LSGAN, target)
+        if self.gan_mode == 'vanilla':      # nn.BCEWithLogitsLoss against the expanded label, loss.py:33-34,63-65
+            target = self.real_label if target_is_real else self.fake_label
+            return ops.LossFn.apply(prediction, None, L.LOSS_BCE_LOGITS, target)
+        if self.gan_mode == 'wgangp':       # loss.py:66-70
+            return ops.LossFn.apply(prediction, None, L.LOSS_NEG_MEAN if target_is_real else L.LOSS_MEAN, 0.0)
         if isinstance(prediction, list):   # multiscale form, loss.py:71-82
             loss = 0
             for pred_i in prediction:

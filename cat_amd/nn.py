@@ -333,6 +333,30 @@ def spectral_norm(module, name='weight', n_power_iterations=1, eps=1e-12):
     return module
 
 
+def remove_spectral_norm(module, name='weight'):
+    """torch.nn.utils.remove_spectral_norm for a cat_amd Conv2d (the export path, reference inception_modules.py:314-315,341-342): bake
+    weight = weight_orig / sigma with the CURRENT u, v (no power iteration, as SpectralNorm.remove does) into a plain `weight` parameter
+    and drop `weight_orig` / `weight_u` / `weight_v`.  One-time host-driven arithmetic, not part of the step."""
+    if name != 'weight' or 'weight_orig' not in module._parameters:
+        raise ValueError("spectral_norm of '{}' not found in {}".format(name, module))
+    with torch.no_grad():
+        w = module.weight_orig.detach()
+        sigma = torch.dot(module.weight_u, torch.mv(w.reshape(w.shape[0], -1), module.weight_v))
+        baked = w / sigma
+        if w.is_cuda and w.dim() == 4 and w.shape[1] > 1:      # keep the kernels' padded channels_last storage
+            new = ops.padded_weight_like(w.shape, w.device)
+            new.copy_(baked)
+            baked = new
+    if 'weight' in module.__dict__:
+        del module.__dict__['weight']
+    del module._parameters['weight_orig']
+    del module._buffers['weight_u']
+    del module._buffers['weight_v']
+    module.__dict__.pop('_cat_sn_eps', None)
+    module.register_parameter('weight', nn.Parameter(baked))
+    return module
+
+
 def _sn_weight(module):
     w = module.weight_orig
     if w.is_cuda and ops.weight_wcs(w) != ops.cs_for(w.shape[1]):

@@ -154,7 +154,8 @@ int cat_ka_bwd(const float* X, int64_t Dx, int N, const float* gout, const void*
 /* Scalar losses with their gradients (models/modules/loss.py:52-99, nn.L1Loss / nn.MSELoss):
  *   kind 0: mean |a-b|      (L1, b tensor)          kind 1: mean (a-t)^2  (lsgan; t scalar target)
  *   kind 2: -mean min(a-1,0)  (hinge D real)        kind 3: -mean min(-a-1,0) (hinge D fake)
- *   kind 4: -mean a           (hinge G)              kind 5: mean (a-b)^2 (MSE vs tensor)
+ *   kind 4: -mean a           (hinge G / wgangp real) kind 5: mean (a-b)^2 (MSE vs tensor)
+ *   kind 6: mean BCE-with-logits(a, target) (vanilla) kind 7: mean a (wgangp fake)
  * Inputs are NHWC with (C, cs); the mean runs over M*C real elements.  out[0] = loss. */
 size_t cat_loss_ws_bytes(int64_t M);
 int cat_loss_fwd(int kind, const float* a, const float* b, float target, int64_t M, int C, int cs, float* out,

@@ -186,3 +186,27 @@ def test_frozen_plan_cache_follows_optimizer_steps():
         optim._bump_weights_epoch()
         w3, _ = cnn._folded_eval_bn(conv, bn, 0)
     assert w2 is not w1 and w3 is not w2 and torch.allclose(w3, 2 * w1)
+
+
+def test_remove_spectral_norm_matches_torch():
+    """cnn.remove_spectral_norm bakes weight_orig / sigma with the current u, v exactly like torch.nn.utils.remove_spectral_norm
+    (the export path, reference inception_modules.py:314-315)."""
+    import torch
+    from cat_amd import nn as cnn
+    torch.manual_seed(5)
+    mine = cnn.spectral_norm(cnn.Conv2d(6, 5, 3, padding=1))
+    twin = torch.nn.utils.spectral_norm(torch.nn.Conv2d(6, 5, 3, padding=1))
+    with torch.no_grad():
+        twin.weight_orig.copy_(mine.weight_orig)
+        twin.bias.copy_(mine.bias)
+        twin.weight_u.copy_(mine.weight_u)
+        twin.weight_v.copy_(mine.weight_v)
+    twin.eval()
+    torch.nn.utils.remove_spectral_norm(twin)
+    cnn.remove_spectral_norm(mine)
+    assert sorted(mine.state_dict().keys()) == sorted(twin.state_dict().keys()) == ['bias', 'weight']
+    assert isinstance(mine.weight, torch.nn.Parameter)
+    assert torch.allclose(mine.weight, twin.weight, rtol=1e-6, atol=1e-7)
+    import pytest
+    with pytest.raises(ValueError):
+        cnn.remove_spectral_norm(mine)

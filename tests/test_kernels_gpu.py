@@ -329,7 +329,7 @@ def test_gan_and_recon_losses(dev):
     from cat_amd.loss import GANLoss, L1Loss, MSELoss
     g = H.load('small_ops.npz')
     pred = detfill.normal((2, 1, 6, 6), 300, 1.5)
-    for mode in ('hinge', 'lsgan'):
+    for mode in ('hinge', 'lsgan', 'vanilla', 'wgangp'):
         crit = GANLoss(mode)
         for real in (True, False):
             p = _nhwc(pred, dev, True)

@@ -23,7 +23,7 @@ def test_ka_and_gan_losses():
         assert abs(v.item() - float(g[f'ka{n}'])) < 1e-6
         assert H.rel_err(X.grad.numpy(), g[f'ka{n}_grad']) < TOL
     pred = detfill.normal((2, 1, 6, 6), 300, 1.5)
-    for mode in ('hinge', 'lsgan'):
+    for mode in ('hinge', 'lsgan', 'vanilla', 'wgangp'):
         for real in (True, False):
             p = pred.clone().requires_grad_(True)
             l = ref_cpu.gan_loss(mode, p, real, True)

@@ -208,7 +208,7 @@ def small_ops():
         out[f'ka{n}'] = np.float64(v.item())
         out[f'ka{n}_grad'] = X.grad.numpy().copy()
     pred = detfill.normal((2, 1, 6, 6), 300, 1.5)
-    for mode in ('hinge', 'lsgan'):
+    for mode in ('hinge', 'lsgan', 'vanilla', 'wgangp'):
         crit = GANLoss(mode)
         for real in (True, False):
             p = pred.clone().requires_grad_(True)
@@ -344,6 +344,9 @@ def eval_utils_golden():
 
 
 if __name__ == '__main__':
+    if os.environ.get('GOLDEN_ONLY') == 'small':
+        small_ops()
+        sys.exit(0)
     if os.environ.get('GOLDEN_ONLY') == 'eval':
         eval_utils_golden()
         sys.exit(0)
