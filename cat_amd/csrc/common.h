@@ -39,6 +39,8 @@ int smallco_fwd_ksplit(const cat_conv_t* g);   // > 1: channel-split forward, ne
 int smallco_fwd(const cat_conv_t* g, const float* x, const float* w, const float* bias, float* y, float* ws, int ksplit, hipStream_t s);
 int smallco_wgrad_nblk(const cat_conv_t* g);
 int smallco_wgrad(const cat_conv_t* g, const float* x, const float* dy, float* ws, hipStream_t s);
+bool smallci_dgrad_applicable(const cat_conv_t* g);   // 4x4 / stride 2 / pad 1 conv with 3 or 6 input channels (PatchGAN's first layer)
+int smallci_dgrad(const cat_conv_t* g, const float* dy, const float* w, float* dx, int dxcs, int dxcw, hipStream_t s);
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }

@@ -1930,6 +1930,10 @@ static int conv_dgrad_impl(const cat_conv_t* g, const float* dy, const float* w,
                                                                             a.slope);      \
     }                                                                                      \
   }
+  if (a.ksplit == 1 && !bias && a.act == CAT_ACT_NONE && cat::smallci_dgrad_applicable(g)) {
+    cat::ProfScope prof("conv_dgrad_smallci", prof_flops, 0.0, stream);
+    return cat::smallci_dgrad(g, dy, w, dx, dxcs, a.cw, s);
+  }
   // BK = 32 variant of the 128 x 128 tile (the discriminator's and the teacher's wide layers)
   static const int bk32 = getenv("CAT_DGRAD_BK32") ? atoi(getenv("CAT_DGRAD_BK32")) : 1;
   if (bk32 && a.ksplit == 1 && dgrad32d_ok(g) && a.c4 == g->Cout) {

@@ -213,6 +213,116 @@ __global__ __launch_bounds__(256) void wgrad_kernel(Args p) {
   }
 }
 
+
+// dgrad of a 4x4 / stride 2 / pad 1 conv with 3 or 6 INPUT channels (PatchGAN's first layer: the gradient into the image).
+// GEMM-N = Cin would be >= 62 % MFMA padding, and the implicit-GEMM kernel walks the taps in the outer K loop, so its four shifted reads
+// of dy miss L2 (measured 18x the compulsory fetch).  Here dy is staged ONCE per 16-channel chunk in LDS and every output pixel class
+// (parity of iy + pad, ix + pad) is one wave: class (py, px) at coarse position (a, b) is
+//     dx[2a + py - pad][2b + px - pad][ci] = sum_{jy, jx in {0,1}} sum_co dy[a - jy][b - jx][co] * w[co][py + 2 jy][px + 2 jx][ci]
+// Thread (ty, sx) of a class owns the 8 coarse pixels (ty + 8 u, sx + 8 i), u < 2, i < 4.  The class's filter taps of the chunk sit in LDS
+// as [tap][quad][co-in-quad][CI] and are read as broadcast b128 (scalar loads would share lgkmcnt with the LDS reads and serialise).
+template <int CI, int CKQ>
+__global__ __launch_bounds__(256) void dgrad_s2_kernel(Args p) {
+  constexpr int TH = 16, TR = TH + 2, NC = 34, TC = 40, PLANE = TR * TC;
+  constexpr int WQ = 4 * CI;                     // floats per (tap, quad): 4 output channels of the forward conv x CI
+  static_assert(CKQ == 4 && (WQ & 3) == 0, "filter stage: one (class, tap, quad, co) row per thread");
+  __shared__ __attribute__((aligned(16))) f4 tile[CKQ * PLANE];
+  __shared__ __attribute__((aligned(16))) float wl[4 * 4 * CKQ * WQ];
+  const int tid = threadIdx.x;
+  const int pl = tid & 63;
+  const int cls = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int py = cls >> 1, px = cls & 1;
+  const int ty = pl >> 3, sx = pl & 7;
+  const int n = blockIdx.y;
+  const int a0 = (blockIdx.x / p.tiles_x) * TH, b0 = (blockIdx.x % p.tiles_x) * 32;
+  // first coarse row / column of this class whose output pixel is >= 0, and that pixel's coordinate
+  const int amy = p.pad > py ? (p.pad - py + 1) >> 1 : 0, amx = p.pad > px ? (p.pad - px + 1) >> 1 : 0;
+  const int fy = 2 * amy + py - p.pad, fx = 2 * amx + px - p.pad;
+  float acc[8][CI];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int c = 0; c < CI; ++c) acc[i][c] = 0.f;
+  const float* dyn = p.dy + (int64_t)n * p.Ho * p.Wo * p.ycs;
+  const int nquads = p.c4 / 4;       // c4 = round_up(Cout, 4)
+  // filter stage map: thread -> (class, tap, quad, co-in-quad)
+  const int we = tid & 3, wq = (tid >> 2) & 3, wt = (tid >> 4) & 3, wc = tid >> 6;
+  const int wky = (wc >> 1) + 2 * (wt >> 1), wkx = (wc & 1) + 2 * (wt & 1);
+  for (int q0 = 0; q0 < nquads; q0 += CKQ) {
+    const int nq = min(CKQ, nquads - q0);
+    constexpr int ITERS = (TR * NC * CKQ + 255) / 256;
+    f4 buf[ITERS];
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+      const int idx = tid + it * 256;
+      const int q = idx % CKQ, pix = idx / CKQ;
+      const int r = pix / NC, c = pix - r * NC;
+      const int oy = a0 - 1 + r, ox = b0 - 1 + c;
+      f4 v = {0.f, 0.f, 0.f, 0.f};
+      if (idx < TR * NC * CKQ && q < nq && (unsigned)oy < (unsigned)p.Ho && (unsigned)ox < (unsigned)p.Wo)
+        v = *reinterpret_cast<const f4*>(dyn + ((int64_t)oy * p.Wo + ox) * p.ycs + (q0 + q) * 4);
+      buf[it] = v;
+    }
+    float wr[CI];
+    {
+      const int co = (q0 + wq) * 4 + we;
+      const float* wp = p.w + ((int64_t)min(co, p.Cout - 1) * 16 + wky * 4 + wkx) * p.wcs;
+#pragma unroll
+      for (int c = 0; c < CI; ++c) wr[c] = co < p.Cout ? wp[c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+      const int idx = tid + it * 256;
+      const int q = idx % CKQ, pix = idx / CKQ;
+      const int r = pix / NC, c = pix - r * NC;
+      if (idx < TR * NC * CKQ) tile[q * PLANE + r * TC + c] = buf[it];
+    }
+#pragma unroll
+    for (int c = 0; c < CI; ++c) wl[((wc * 4 + wt) * CKQ + wq) * WQ + we * CI + c] = wr[c];
+    __syncthreads();
+    for (int q = 0; q < nq; ++q) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int jy = t >> 1, jx = t & 1;
+        const f4* wrow = reinterpret_cast<const f4*>(wl + ((cls * 4 + t) * CKQ + q) * WQ);
+        float wv[WQ];
+#pragma unroll
+        for (int k = 0; k < WQ / 4; ++k) {
+          const f4 v = wrow[k];
+          wv[4 * k] = v[0]; wv[4 * k + 1] = v[1]; wv[4 * k + 2] = v[2]; wv[4 * k + 3] = v[3];
+        }
+        const f4* row = tile + q * PLANE + (ty + amy - jy + 1) * TC + sx + amx - jx + 1;
+        f4 xv[8];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) xv[u * 4 + i] = row[u * 8 * TC + 8 * i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int c = 0; c < CI; ++c)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i][c] = fmaf(xv[i][e], wv[e * CI + c], acc[i][c]);
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int iy = 2 * (a0 + ty + 8 * u) + fy;
+    if (iy >= p.H) continue;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int ix = 2 * (b0 + sx + 8 * i) + fx;
+      if (ix >= p.W) continue;
+      float* o = p.y + (((int64_t)n * p.H + iy) * p.W + ix) * p.xcs;
+#pragma unroll
+      for (int c = 0; c < CI; ++c) o[c] = acc[u * 4 + i][c];
+      for (int c = CI; c < p.cw; ++c) o[c] = 0.f;
+    }
+  }
+}
+
 }  // namespace cat_smallco
 
 namespace cat {
@@ -317,6 +427,31 @@ int smallco_wgrad(const cat_conv_t* g, const float* x, const float* dy, float* w
     cat_smallco::wgrad_kernel<4, 16, 4, 7><<<dim3(nb, cdiv(a.c4 / 4, 4)), 256, 0, s>>>(a);
   }
   return check_launch("conv2d_wgrad_smallco");
+}
+
+
+// dgrad of PatchGAN's first layer (see dgrad_s2_kernel): 4x4, stride 2, zero pad 1, 3 or 6 input channels
+bool smallci_dgrad_applicable(const cat_conv_t* g) {
+  static const int on = getenv("CAT_SMALLCI_DGRAD") ? atoi(getenv("CAT_SMALLCI_DGRAD")) : 1;
+  const int wcs = g->wcs > 0 ? g->wcs : g->Cin;
+  return on && (g->Cin == 3 || g->Cin == 6) && g->stride == 2 && g->kh == 4 && g->kw == 4 && g->pad == 1 && g->pad_mode == CAT_PAD_ZERO &&
+         g->Cout >= 16 && wcs >= g->Cin && (g->ycs & 3) == 0;
+}
+
+// dx: [N, H, W, dxcs], channels [Cin, dxcw) zero-filled
+int smallci_dgrad(const cat_conv_t* g, const float* dy, const float* w, float* dx, int dxcs, int dxcw, hipStream_t s) {
+  cat_smallco::Args a = make_args(g);
+  a.dy = dy; a.w = w; a.y = dx;
+  a.xcs = dxcs;
+  a.cw = dxcw > g->Cin ? dxcw : g->Cin;
+  a.c4 = (g->Cout + 3) & ~3;
+  // coarse class grid: every class has at most ceil(H / 2) x ceil(W / 2) pixels
+  a.tiles_x = cdiv(cdiv(g->W, 2), 32);
+  a.tiles_y = cdiv(cdiv(g->H, 2), 16);
+  const dim3 grid(a.tiles_x * a.tiles_y, g->N);
+  if (g->Cin == 6) cat_smallco::dgrad_s2_kernel<6, 4><<<grid, 256, 0, s>>>(a);
+  else cat_smallco::dgrad_s2_kernel<3, 4><<<grid, 256, 0, s>>>(a);
+  return check_launch("conv2d_dgrad_smallci");
 }
 
 }  // namespace cat

@@ -74,6 +74,10 @@ CONV_CASES = [
     (256, 128, 4, 1, 1, False, 0, 2, 11, 32),
     (128, 130, 3, 2, 1, False, 0, 2, 9, 64),
     (512, 1, 4, 1, 2, False, 0, 2, 9, 17),
+    # PatchGAN's first layer: the image gradient through the class-per-wave 4x4 / stride 2 dgrad (3 and 6 channels, ragged and odd planes)
+    (3, 64, 4, 2, 1, False, 2, 2, 70, 50),
+    (6, 20, 4, 2, 1, False, 0, 1, 33, 37),
+    (6, 128, 4, 2, 1, False, 2, 2, 64, 96),
 ]
 
 
