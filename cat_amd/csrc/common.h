@@ -42,6 +42,11 @@ int smallco_wgrad(const cat_conv_t* g, const float* x, const float* dy, float* w
 bool smallci_dgrad_applicable(const cat_conv_t* g);   // 4x4 / stride 2 / pad 1 conv with 3 or 6 input channels (PatchGAN's first layer)
 int smallci_dgrad(const cat_conv_t* g, const float* dy, const float* w, float* dx, int dxcs, int dxcw, hipStream_t s);
 
+// LDS-tile weight gradient of narrow stride-1 3x3 / 5x5 layers (conv_twgrad.hip)
+bool twgrad_applicable(const cat_conv_t* g);
+int twgrad_nblk(const cat_conv_t* g);
+int twgrad(const cat_conv_t* g, const float* x, const float* dy, float* ws, hipStream_t s);   // partials [nblk][Cout][taps * round_up(Cin, 4)]
+
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 

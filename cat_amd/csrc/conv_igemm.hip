@@ -1525,30 +1525,50 @@ __global__ __launch_bounds__(256) void weight_transpose_kernel(const float* __re
   }
 }
 
-// dw[co][tap][ci] (+)= sum_z ws[z][co][tap*c4 + ci]; 64 outputs x 4 split-lanes per workgroup (coalesced in ci)
+// dw[co][tap][ci] (+)= sum_z ws[z][co][tap*c4 + ci].  Workgroup = 16 channel quads x 16 split lanes: every thread sums its slices' float4 in
+// increasing z (fixed order), the 16 lanes of a quad are then combined pairwise through LDS -- deterministic, and 16-byte loads with 16
+// slices in flight per output instead of 4-byte loads with 4.
 // wlim = channels written per tap (Cin for dense storage, the padded extent otherwise), wcs = storage stride per tap
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nsplit,
                                                            int Cout, int taps, int wlim, int wcs, int c4, int K, int accumulate) {
-  __shared__ float red[256];
-  const int64_t total = (int64_t)Cout * taps * wlim;
-  const int64_t e = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
-  const int zl = threadIdx.x >> 6;
-  float s = 0.f;
-  int64_t dst = 0;
+  __shared__ f4 red[256];
+  const int cq = c4 >> 2;
+  const int64_t total = (int64_t)Cout * taps * cq;
+  const int64_t e = (int64_t)blockIdx.x * 16 + (threadIdx.x & 15);
+  const int zl = threadIdx.x >> 4;
+  f4 s = {0.f, 0.f, 0.f, 0.f};
+  int q = 0, tap = 0, co = 0;
   if (e < total) {
-    const int ci = (int)(e % wlim);
-    const int64_t ct = e / wlim;
-    const int tap = (int)(ct % taps), co = (int)(ct / taps);
-    dst = ((int64_t)co * taps + tap) * wcs + ci;
-    const float* src = ws + (int64_t)co * K + tap * c4 + ci;
-    for (int z = zl; z < nsplit; z += 4) s += src[(int64_t)z * Cout * K];
+    q = (int)(e % cq);
+    const int64_t ct = e / cq;
+    tap = (int)(ct % taps);
+    co = (int)(ct / taps);
+    const float* src = ws + (int64_t)co * K + tap * c4 + q * 4;
+    const int64_t zs = (int64_t)Cout * K;
+    int z = zl;
+    for (; z + 48 < nsplit; z += 64) {
+      const f4 v0 = *reinterpret_cast<const f4*>(src + z * zs), v1 = *reinterpret_cast<const f4*>(src + (z + 16) * zs);
+      const f4 v2 = *reinterpret_cast<const f4*>(src + (z + 32) * zs), v3 = *reinterpret_cast<const f4*>(src + (z + 48) * zs);
+      s += v0;
+      s += v1;
+      s += v2;
+      s += v3;
+    }
+    for (; z < nsplit; z += 16) s += *reinterpret_cast<const f4*>(src + z * zs);
   }
   red[threadIdx.x] = s;
   __syncthreads();
+#pragma unroll
+  for (int st = 8; st >= 1; st >>= 1) {
+    if (zl < st) red[threadIdx.x] += red[threadIdx.x + st * 16];
+    __syncthreads();
+  }
   if (zl == 0 && e < total) {
-    const int l = threadIdx.x;
-    s = (red[l] + red[l + 64]) + (red[l + 128] + red[l + 192]);
-    dw[dst] = accumulate ? dw[dst] + s : s;
+    const f4 r = red[threadIdx.x];
+    float* d = dw + ((int64_t)co * taps + tap) * wcs + q * 4;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (q * 4 + c < wlim) d[c] = accumulate ? d[c] + r[c] : r[c];
   }
 }
 
@@ -1992,6 +2012,7 @@ size_t cat_conv2d_wgrad_ws_bytes(const cat_conv_t* g) {
   const WgradPlan pl = wgrad_plan(g);
   const size_t K = (size_t)g->kh * g->kw * ((g->Cin + 3) & ~3);
   if (cat::smallco_applicable(g)) return (size_t)cat::smallco_wgrad_nblk(g) * g->Cout * K * sizeof(float);
+  if (cat::twgrad_applicable(g)) return (size_t)cat::twgrad_nblk(g) * g->Cout * K * sizeof(float);
   return (size_t)pl.nsplit * g->Cout * K * sizeof(float);
 }
 
@@ -2015,12 +2036,21 @@ int cat_conv2d_wgrad(const cat_conv_t* g, const float* x, const float* dy, float
     const double fl = 2.0 * (double)g->N * g->Ho * g->Wo * g->Cout * g->kh * g->kw * g->Cin;
     cat::ProfScope prof("conv_wgrad_smallco", fl, 0.0, stream);
     if (int e = cat::smallco_wgrad(g, x, dy, (float*)ws, s)) return e;
-    const int64_t total = (int64_t)a.Cout * a.kh * a.kw * a.cval;
-    wgrad_reduce_kernel<<<(int)((total + 63) / 64), 256, 0, s>>>((const float*)ws, dw, cat::smallco_wgrad_nblk(g), a.Cout, a.kh * a.kw,
+    const int64_t total = (int64_t)a.Cout * a.kh * a.kw * (a.c4 / 4);
+    wgrad_reduce_kernel<<<(int)((total + 15) / 16), 256, 0, s>>>((const float*)ws, dw, cat::smallco_wgrad_nblk(g), a.Cout, a.kh * a.kw,
                                                                   a.cval, a.wcs, a.c4, a.K, accumulate);
     return cat::check_launch("conv2d_wgrad_reduce");
   }
   const double prof_flops = 2.0 * (double)g->N * g->Ho * g->Wo * g->Cout * g->kh * g->kw * g->Cin;
+  if (cat::twgrad_applicable(g)) {
+    CAT_REQUIRE(ws != nullptr, "conv wgrad: workspace required");
+    cat::ProfScope prof("conv_twgrad", prof_flops, 0.0, stream);
+    if (int e = cat::twgrad(g, x, dy, (float*)ws, s)) return e;
+    const int64_t total = (int64_t)a.Cout * a.kh * a.kw * (a.c4 / 4);
+    wgrad_reduce_kernel<<<(int)((total + 15) / 16), 256, 0, s>>>((const float*)ws, dw, cat::twgrad_nblk(g), a.Cout, a.kh * a.kw, a.cval, a.wcs, a.c4,
+                                                                  a.K, accumulate);
+    return cat::check_launch("conv2d_wgrad_reduce");
+  }
   int rows_per = 0;
   if (const int nsd = wgrad32d_nsplit(g, &rows_per)) {
     CAT_REQUIRE(nsd == 1 || ws != nullptr, "conv wgrad: workspace required");
@@ -2040,8 +2070,8 @@ int cat_conv2d_wgrad(const cat_conv_t* g, const float* x, const float* dy, float
     }
     if (int e = cat::check_launch("conv2d_wgrad")) return e;
     if (!a.direct) {
-      const int64_t total = (int64_t)a.Cout * a.kh * a.kw * a.cval;
-      wgrad_reduce_kernel<<<(int)((total + 63) / 64), 256, 0, s>>>((const float*)ws, dw, nsd, a.Cout, a.kh * a.kw, a.cval, a.wcs, a.c4, a.K,
+      const int64_t total = (int64_t)a.Cout * a.kh * a.kw * (a.c4 / 4);
+      wgrad_reduce_kernel<<<(int)((total + 15) / 16), 256, 0, s>>>((const float*)ws, dw, nsd, a.Cout, a.kh * a.kw, a.cval, a.wcs, a.c4, a.K,
                                                                     accumulate);
       return cat::check_launch("conv2d_wgrad_reduce");
     }
@@ -2063,8 +2093,8 @@ int cat_conv2d_wgrad(const cat_conv_t* g, const float* x, const float* dy, float
 #undef LAUNCH
   if (int e = cat::check_launch("conv2d_wgrad")) return e;
   if (!a.direct) {
-    const int64_t total = (int64_t)a.Cout * a.kh * a.kw * a.cval;
-    const int grid = (int)((total + 63) / 64);
+    const int64_t total = (int64_t)a.Cout * a.kh * a.kw * (a.c4 / 4);
+    const int grid = (int)((total + 15) / 16);
     wgrad_reduce_kernel<<<grid, 256, 0, s>>>((const float*)ws, dw, pl.nsplit, a.Cout, a.kh * a.kw, a.cval, a.wcs, a.c4, a.K, accumulate);
     return cat::check_launch("conv2d_wgrad_reduce");
   }

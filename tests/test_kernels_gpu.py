@@ -130,6 +130,10 @@ TCONV_CASES = [
     # cin, cout, k, reflect, act, N, H, W
     (77, 18, 5, True, 0, 4, 48, 64), (18, 77, 5, True, 0, 4, 48, 64), (77, 12, 3, False, 2, 4, 48, 64), (9, 77, 5, False, 0, 3, 50, 70),
     (256, 42, 5, True, 0, 4, 56, 64), (42, 256, 3, True, 0, 4, 56, 64), (23, 130, 3, False, 0, 3, 61, 67), (16, 16, 3, True, 3, 4, 48, 64),
+    # the LDS-tile weight gradient (csrc/conv_twgrad.hip): wide x / narrow dy and the reverse, 5x5 and 3x3, one and two narrow tiles,
+    # reflect and zero padding, ragged plane edges, a wide side of three tiles
+    (77, 15, 5, True, 0, 4, 64, 64), (15, 77, 5, True, 0, 4, 64, 64), (77, 9, 5, False, 0, 3, 61, 67), (13, 77, 3, False, 0, 3, 61, 67),
+    (77, 18, 3, True, 0, 4, 64, 64), (18, 77, 3, True, 0, 4, 64, 64), (40, 12, 3, True, 0, 4, 64, 48),
 ]
 
 
@@ -159,6 +163,10 @@ def test_conv2d_lds_tile_fwd_bwd(dev, cin, cout, k, reflect, act, n, h, w):
     fam = _families()
     lib.cat_prof_enable(0)
     assert fam.get('conv_tconv', 0) == 2, fam          # forward + input gradient both ran on the LDS-tile kernel
+    tl = lambda c: ((c + 3) // 4 * 4 + 15) // 16
+    narrow, wide = sorted((tl(cin), tl(cout)))
+    if max(cin, cout) <= 80 and narrow <= (1 if k == 5 else 2) and wide >= 3 and n * ((h + 7) // 8) * ((w + 7) // 8) >= 128:
+        assert fam.get('conv_twgrad', 0) == 1, fam     # ... and the weight gradient on the LDS-tile wgrad kernel
     assert rel(y, yr) < TOL
     cs = ops.act_cs(y)
     full = torch.as_strided(y, (y.shape[0], cs, y.shape[2], y.shape[3]), y.stride())
