@@ -151,6 +151,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--sustained-steps', type=int, default=100, help='extra steps after the timed region (N=1): the clock-settled rate')
     ap.add_argument('--workload', default='c2', choices=['c2', 'spade'],
                     help='c2 = pix2pix InceptionDistiller (BASELINE configs[1], the headline metric); spade = GauGAN SPADEDistiller '
                          '(configs[3], per-GPU batch 4 @ 512x256)')
@@ -255,6 +256,19 @@ def main():
     losses = model.get_current_losses()
     assert all(v == v for v in losses.values()), 'NaN loss'
     assert ops.STATS['conform_copies'] == 0
+    # sustained rate: `value` above is the contract's K steps (the driver asks for 20: ~1 s of GPU work, inside the boost window and below an
+    # external utilisation sampler's cadence).  A second, longer run of the SAME step shows the clock-settled rate and keeps the GPU busy
+    # for several seconds; reported beside `value`, never instead of it.
+    sustained = None
+    if world == 1 and args.sustained_steps > 0:
+        barrier()
+        t1 = time.perf_counter()
+        for i in range(args.sustained_steps):
+            step(args.warmup + args.steps + i)
+        barrier()
+        ds = time.perf_counter() - t1
+        sustained = {'steps': args.sustained_steps, 'ms_per_step': round(1e3 * ds / args.sustained_steps, 3),
+                     'value': round(args.batch * args.sustained_steps / ds, 3)}
 
     # the measurement passes run the step / the student forward again: with N > 1 ranks those contain collectives (gradient buckets,
     # SynchronizedBatchNorm statistics), so EVERY rank executes them; rank 0 reports
@@ -288,6 +302,8 @@ def main():
         'roofline': roofline,
         'student_forward': student_fwd,
     }
+    if sustained is not None:
+        out['sustained'] = sustained
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = (cpu_baseline_spade if spade else cpu_baseline)(opt, model, args)

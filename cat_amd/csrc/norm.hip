@@ -61,10 +61,19 @@ __global__ __launch_bounds__(256) void norm_stats_kernel(const float* __restrict
     const int c = cq * 4;
     if (MODE == 0) {
       const f4 sh = *reinterpret_cast<const f4*>(xg + c);
-      for (int p = pbeg + pl; p < pend; p += ppl) {
-        const f4 v = *reinterpret_cast<const f4*>(xg + (int64_t)p * cs + c) - sh;
-        s0 += v;
-        s1 += v * v;
+      for (int p0 = pbeg + pl; p0 < pend; p0 += 4 * ppl) {
+        f4 q[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int p = p0 + k * ppl;
+          q[k] = p < pend ? *reinterpret_cast<const f4*>(xg + (int64_t)p * cs + c) : sh;      // x - x0 = 0: adds nothing
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const f4 v = q[k] - sh;
+          s0 += v;
+          s1 += v * v;
+        }
       }
     } else {
       const float* dg = dy + (int64_t)g * Pg * cs;
@@ -77,16 +86,26 @@ __global__ __launch_bounds__(256) void norm_stats_kernel(const float* __restrict
         ga[e] = cv ? (gamma ? gamma[c + e] : 1.f) : 0.f;
         be[e] = cv ? (beta ? beta[c + e] : 0.f) : 0.f;
       }
-      for (int p = pbeg + pl; p < pend; p += ppl) {
-        const f4 xv = *reinterpret_cast<const f4*>(xg + (int64_t)p * cs + c);
-        f4 gv = *reinterpret_cast<const f4*>(dg + (int64_t)p * cs + c);
-        const f4 xh = (xv - mu) * rs;
-        if (act != CAT_ACT_NONE) {
+      for (int p0 = pbeg + pl; p0 < pend; p0 += 4 * ppl) {      // four independent pixels per iteration: more loads in flight
+        f4 xq[4], gq[4];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) gv[e] *= cat::act_grad_from_out(cat::apply_act(ga[e] * xh[e] + be[e], act, slope), act, slope);
+        for (int k = 0; k < 4; ++k) {
+          const int p = p0 + k * ppl;
+          const bool v = p < pend;
+          xq[k] = v ? *reinterpret_cast<const f4*>(xg + (int64_t)p * cs + c) : mu;     // xhat = 0, g = 0: adds nothing
+          gq[k] = v ? *reinterpret_cast<const f4*>(dg + (int64_t)p * cs + c) : f4{0.f, 0.f, 0.f, 0.f};
         }
-        s0 += gv;
-        s1 += gv * xh;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {      // same summation order as the one-pixel loop
+          const f4 xh = (xq[k] - mu) * rs;
+          f4 gv = gq[k];
+          if (act != CAT_ACT_NONE) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) gv[e] *= cat::act_grad_from_out(cat::apply_act(ga[e] * xh[e] + be[e], act, slope), act, slope);
+          }
+          s0 += gv;
+          s1 += gv * xh;
+        }
       }
     }
   }
@@ -251,6 +270,102 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* __rest
   }
 }
 
+// Pixel-walk variants of the two apply passes: a thread owns ONE channel quad (its per-(group, channel) coefficients live in registers for the
+// whole walk) and strides over the pixels of its block, four independent pixels per iteration -- no per-element index division and no
+// per-element coefficient loads (the element-walk kernels issue 5 - 13 loads per float4 of payload), more loads in flight per wave.
+__global__ __launch_bounds__(256) void norm_apply_walk_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                              const float* __restrict__ shift, float* __restrict__ y, int Pg, int cs, int zq,
+                                                              int ppl, int nb, int act, float slope) {
+  const int g = blockIdx.y, b = blockIdx.x, z = blockIdx.z;
+  const int cq = z * zq + threadIdx.x % zq, pl = threadIdx.x / zq;
+  if (pl >= ppl || cq * 4 >= cs) return;
+  const int per = (Pg + nb - 1) / nb;
+  const int pbeg = b * per, pend = min(Pg, pbeg + per);
+  const int c = cq * 4;
+  const f4 sc = *reinterpret_cast<const f4*>(scale + g * cs + c), sh = *reinterpret_cast<const f4*>(shift + g * cs + c);
+  const float* xg = x + (int64_t)g * Pg * cs + c;
+  float* yg = y + (int64_t)g * Pg * cs + c;
+  for (int p0 = pbeg + pl; p0 < pend; p0 += 4 * ppl) {
+    f4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int p = p0 + k * ppl;
+      v[k] = p < pend ? *reinterpret_cast<const f4*>(xg + (int64_t)p * cs) : f4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int p = p0 + k * ppl;
+      f4 o = v[k] * sc + sh;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = cat::apply_act(o[e], act, slope);
+      if (p < pend) *reinterpret_cast<f4*>(yg + (int64_t)p * cs) = o;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void norm_bwd_apply_walk_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                  const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                  const float* __restrict__ c1, const float* __restrict__ c2,
+                                                                  const float* __restrict__ scale, float* __restrict__ dx, int Pg, int C, int cs,
+                                                                  int zq, int ppl, int nb, int act, float slope) {
+  const int g = blockIdx.y, b = blockIdx.x, z = blockIdx.z;
+  const int cq = z * zq + threadIdx.x % zq, pl = threadIdx.x / zq;
+  if (pl >= ppl || cq * 4 >= cs) return;
+  const int per = (Pg + nb - 1) / nb;
+  const int pbeg = b * per, pend = min(Pg, pbeg + per);
+  const int c = cq * 4;
+  const f4 m1 = *reinterpret_cast<const f4*>(c1 + g * cs + c), m2 = *reinterpret_cast<const f4*>(c2 + g * cs + c);
+  const f4 sc = *reinterpret_cast<const f4*>(scale + g * cs + c);
+  f4 mu, rs, ga, be;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const bool cv = c + e < C;
+    mu[e] = cv ? mean[g * C + c + e] : 0.f;
+    rs[e] = cv ? rstd[g * C + c + e] : 0.f;
+    ga[e] = cv ? (gamma ? gamma[c + e] : 1.f) : 0.f;
+    be[e] = cv ? (beta ? beta[c + e] : 0.f) : 0.f;
+  }
+  const float* xg = x + (int64_t)g * Pg * cs + c;
+  const float* dg = dy + (int64_t)g * Pg * cs + c;
+  float* og = dx + (int64_t)g * Pg * cs + c;
+  for (int p0 = pbeg + pl; p0 < pend; p0 += 4 * ppl) {
+    f4 xv[4], gv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int p = p0 + k * ppl;
+      const bool v = p < pend;
+      xv[k] = v ? *reinterpret_cast<const f4*>(xg + (int64_t)p * cs) : f4{0.f, 0.f, 0.f, 0.f};
+      gv[k] = v ? *reinterpret_cast<const f4*>(dg + (int64_t)p * cs) : f4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int p = p0 + k * ppl;
+      f4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float xh = (xv[k][e] - mu[e]) * rs[e];
+        float gg = gv[k][e];
+        if (act != CAT_ACT_NONE) gg *= cat::act_grad_from_out(cat::apply_act(ga[e] * xh + be[e], act, slope), act, slope);
+        o[e] = sc[e] * (gg - m1[e] - xh * m2[e]);
+      }
+      if (p < pend) *reinterpret_cast<f4*>(og + (int64_t)p * cs) = o;
+    }
+  }
+}
+
+// block count of the apply walks: ~4096 workgroups, at least 8 pixels per pixel lane
+static int walk_blocks(const NormPlan& p) {
+  int nb = cdiv(4096, p.G * p.nz);
+  const int maxb = cdiv(p.Pg, p.ppl * 8);
+  if (nb > maxb) nb = maxb;
+  return nb < 1 ? 1 : nb;
+}
+static bool walk_on() {
+  static const int on = getenv("CAT_NORM_WALK") ? atoi(getenv("CAT_NORM_WALK")) : 1;
+  return on != 0;
+}
+
 __global__ void bn_fold_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float eps, int C,
                                float* scale, float* shift) {
   const int c = blockIdx.x * 256 + threadIdx.x;
@@ -308,6 +423,11 @@ int cat_norm_fwd(const cat_norm_t* g, const float* x, const float* gamma, const 
                                                                    w + p.shift_off, p.G, p.Pg, g->C, g->cs, p.nb, g->eps, g->momentum,
                                                                    g->mode == CAT_NORM_BATCH ? num_batches_tracked : nullptr);
   const int64_t nquads = (int64_t)g->N * g->HW * p.nq;
+  if (walk_on()) {
+    const int nbw = walk_blocks(p);
+    norm_apply_walk_kernel<<<dim3(nbw, p.G, p.nz), 256, 0, s>>>(x, w + p.scale_off, w + p.shift_off, y, p.Pg, g->cs, p.zq, p.ppl, nbw, g->act, g->slope);
+    return cat::check_launch("norm_fwd");
+  }
   if (idx32(nquads))
     norm_apply_kernel<int><<<ew_grid(nquads), 256, 0, s>>>(x, w + p.scale_off, w + p.shift_off, y, (int)nquads, p.nq, p.Pg * p.nq, g->cs,
                                                             g->act, g->slope);
@@ -334,6 +454,12 @@ int cat_norm_bwd(const cat_norm_t* g, const float* x, const float* dy, const flo
   if (!one_group && (dgamma || dbeta))
     norm_bwd_param_kernel<<<cdiv(g->C, 256), 256, 0, s>>>(w + p.c1_off, w + p.c2_off, dgamma, dbeta, p.G, p.Pg, g->C, g->cs, accumulate);
   const int64_t nquads = (int64_t)g->N * g->HW * p.nq;
+  if (walk_on()) {
+    const int nbw = walk_blocks(p);
+    norm_bwd_apply_walk_kernel<<<dim3(nbw, p.G, p.nz), 256, 0, s>>>(x, dy, gamma, beta, save_mean, save_rstd, w + p.c1_off, w + p.c2_off,
+                                                                     w + p.scale_off, dx, p.Pg, g->C, g->cs, p.zq, p.ppl, nbw, g->act, g->slope);
+    return cat::check_launch("norm_bwd");
+  }
   if (idx32(nquads))
     norm_bwd_apply_kernel<int><<<ew_grid(nquads), 256, 0, s>>>(x, dy, gamma, beta, save_mean, save_rstd, w + p.c1_off, w + p.c2_off,
                                                                 w + p.scale_off, dx, (int)nquads, p.nq, p.Pg * p.nq, g->C, g->cs, g->act,

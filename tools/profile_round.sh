@@ -14,12 +14,12 @@ python -c 'import __graft_entry__ as g; g.smoke()' > $OUT/smoke.log 2>&1
 fi
 # per-kernel durations are compared with bench.py's SERIAL roofline pass: branch streams off, no in-process event profiling
 export CAT_BRANCH_STREAMS=0
-B="python $PWD/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-profile --graph 0"
+B="python $PWD/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-profile --graph 0 --sustained-steps 0"
 SF="python $PWD/tools/debug/student_fwd_trace.py"
 (cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/prof_c2 -o bench -- $B > $OUT/prof_c2.log 2>&1)
 (cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/prof_spade -o bench -- $B --workload spade > $OUT/prof_spade.log 2>&1)
 if [ -z "$SKIP_PMC" ]; then
-P="python $PWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-profile --graph 0"
+P="python $PWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-profile --graph 0 --sustained-steps 0"
 (cd /tmp && rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc/fetch -o f -- $P > $OUT/pmc_fetch.log 2>&1)
 (cd /tmp && rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc/write -o w -- $P > $OUT/pmc_write.log 2>&1)
 fi
