@@ -27,7 +27,7 @@ fi
 python tools/rocprof_summary.py $OUT/prof_c2/bench_results.db $OUT/kernel_stats_c2.txt 6 > /dev/null
 # the student forward alone (captured graph replays) and the SQ counters of the serial C2 command
 (cd /tmp && REPS=5 rocprofv3 --kernel-trace --stats -d $OUT/prof_sfwd -o sfwd -- $SF > $OUT/prof_sfwd.log 2>&1)
-python tools/rocprof_summary.py $OUT/prof_sfwd/sfwd_results.db $OUT/kernel_stats_student_fwd.txt 9 > /dev/null
+python tools/rocprof_summary.py $OUT/prof_sfwd/sfwd_results.db $OUT/kernel_stats_student_fwd.txt 8 > /dev/null
 if [ -z "$SKIP_PMC" ]; then
 (cd /tmp && rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_WAVES --kernel-trace --output-format csv -d $OUT/pmc_sq -o q -- $P > $OUT/pmc_sq.log 2>&1)
 python tools/pmc_sq_summary.py $OUT/pmc_sq $OUT/pmc_sq_c2.txt > /dev/null 2>&1
