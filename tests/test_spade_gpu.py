@@ -198,6 +198,12 @@ def test_spectral_norm(o, i, k):
         ye = conv(nhwc(x))
         we = R.spectral_norm_weight(sd, 'c', False)
     assert rel(ye, F.conv2d(x, we, None, padding=1)) < 1e-4
+    # export path (reference inception_modules.py:314-315): baking the normalised weight in changes nothing about the eval forward
+    cnn.remove_spectral_norm(conv)
+    assert sorted(conv.state_dict().keys()) == ['weight']
+    with torch.no_grad():
+        yb = conv(nhwc(x))
+    assert rel(yb, ye) < 1e-6
 
 
 def test_disc_input_and_halves():
