@@ -23,4 +23,4 @@ for (cin, cout, k) in ((77, 15, 5), (15, 77, 5), (77, 12, 3), (12, 77, 3)):
     e1.record(); torch.cuda.synchronize()
     gf = 2.0 * n * h * w * cout * k * k * cin / 1e9
     us = e0.elapsed_time(e1) * 1e3 / 50
-    print(f'{cin}->{cout} k{k}: {us:7.1f} us  {gf / us * 1e-3:6.1f} TF   CAT_TWGRAD={os.environ.get("CAT_TWGRAD", "1")}')
+    print(f'{cin}->{cout} k{k}: {us:7.1f} us  {gf / us * 1e3:6.1f} TF   CAT_TWGRAD={os.environ.get("CAT_TWGRAD", "1")}')

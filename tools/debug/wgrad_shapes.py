@@ -35,6 +35,6 @@ tot = 0
 for k, (cnt, us) in sorted(rows.items(), key=lambda kv: -kv[1][1]):
     name, n, h, w, cin, ho, wo, cout, kk, s, p = k
     gf = 2.0 * n * ho * wo * cout * kk * kk * cin / 1e9
-    print(f'{name:18s} N{n} {h}x{w} {cin:4d}->{cout:4d} k{kk} s{s} p{p}  x{cnt}  {us/cnt:8.1f} us  {gf * cnt / us * 1e-3:6.1f} TF' if us else k)
+    print(f'{name:18s} N{n} {h}x{w} {cin:4d}->{cout:4d} k{kk} s{s} p{p}  x{cnt}  {us/cnt:8.1f} us  {gf * cnt / us * 1e3:6.1f} TF' if us else k)
     tot += us
 print('total us', tot)
