@@ -31,14 +31,36 @@ def c2():
     ops.set_tconv_min_tiles(old)
 
 
+@pytest.fixture(scope='module')
+def c2_ragged():
+    """The same networks fed 232 x 232 images, batch 3: a 58 x 58 trunk (ragged 8 x 16 / 8 x 8 tiles on every LDS-tile kernel, 192 tiles
+    for the LDS-tile weight gradient) and a 116 x 116 PatchGAN grid (ragged 16 x 32 coarse tiles of the first layer's image gradient)."""
+    import bench
+    from cat_amd import _lib, ops
+    _lib.load()
+    old = ops.set_tconv_min_tiles(1)
+    args = argparse.Namespace(workload='c2', batch=3, size=232, target_flops=4.6e9)
+    model, opt = bench.build_model(args, 0)
+    yield model, opt
+    ops.set_tconv_min_tiles(old)
+
+
 def test_c2_step_at_256_matches_oracle(c2, capsys):
+    _step_vs_oracle(c2, capsys, 2, 256)
+
+
+def test_c2_step_at_ragged_232_matches_oracle(c2_ragged, capsys):
+    _step_vs_oracle(c2_ragged, capsys, 3, 232)
+
+
+def _step_vs_oracle(fix, capsys, nimg, size):
     from cat_amd import ops
-    model, opt = c2
+    model, opt = fix
     ncfg = {'norm': 'batch', 'eps': opt.norm_epsilon, 'momentum': opt.norm_momentum}
     cfg = dict(T=ncfg, S=ncfg, D=ncfg, dataset_mode='aligned', gan_mode='hinge', lambda_recon=100.0, lambda_distill=1.3, lambda_gan=1.0, lr=opt.lr,
                beta1=opt.beta1)
     st = ref_cpu.DistillState(_cpu(model.netG_teacher), _cpu(model.netG_student), _cpu(model.netD), cfg)
-    A, B = detfill.images((2, 3, 256, 256), 71), detfill.images((2, 3, 256, 256), 72)
+    A, B = detfill.images((nimg, 3, size, size), 71), detfill.images((nimg, 3, size, size), 72)
     ref = ref_cpu.distill_step(st, A, B)
     model.set_input({'A': A, 'B': B, 'A_paths': [], 'B_paths': []})
     ops.STATS['conform_copies'] = 0
@@ -80,7 +102,7 @@ def test_c2_step_at_256_matches_oracle(c2, capsys):
             assert d.max() <= 2.5 * opt.lr + 2e-3 * scale, (name, k, d.max(), scale)
     report['weights_q75'] = worst_q
     with capsys.disabled():
-        print('\n[headline parity @256x256, batch 2] max relative deviation from the CPU oracle: ' + json.dumps({k: float('%.3g' % v) for k, v in report.items()}))
+        print('\n[headline parity @%dx%d, batch %d] max relative deviation from the CPU oracle: ' % (size, size, nimg) + json.dumps({k: float('%.3g' % v) for k, v in report.items()}))
     assert ops.STATS['conform_copies'] == 0
     for k, v in report.items():
         assert v < 1e-3, (k, v)
