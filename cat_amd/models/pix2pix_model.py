@@ -34,8 +34,6 @@ class Pix2PixModel(BaseModel):
         self.loss_names = ['G_gan', 'G_recon', 'D_real', 'D_fake', 'G_comp_cost']
         self.visual_names = ['real_A', 'fake_B', 'real_B']
         self.model_names = ['G', 'D']
-        if getattr(opt, 'lambda_comp_cost', 0) > 0:
-            raise NotImplementedError('lambda_comp_cost > 0 is not used by any training script')
         self.netG = networks.define_G(opt.input_nc, opt.output_nc, opt.ngf, opt.netG, opt.norm, opt.dropout_rate, opt.init_type,
                                       opt.init_gain, self._dev_ids, opt=opt)
         self.netD = networks.define_D(opt.input_nc + opt.output_nc, opt.ndf, opt.netD, opt.n_layers_D, opt.norm, opt.init_type,
@@ -81,6 +79,13 @@ class Pix2PixModel(BaseModel):
         self.loss_G_gan = LossValue([(opt.lambda_gan, gan)])
         self.loss_G_recon = LossValue([(opt.lambda_recon, recon)])
         self.loss_G = self.loss_G_gan + self.loss_G_recon
+        if getattr(opt, 'lambda_comp_cost', 0) > 0:
+            # pix2pix_model.py:186-195: the term is netG.get_comp_cost(...) * lambda, and NO generator of the reference defines
+            # get_comp_cost -- its getattr default returns 0, so the flag only adds a zero `G_comp_cost` entry to the loss report
+            cost = getattr(self.netG, 'get_comp_cost', lambda p, renorm: 0)(p=int(opt.comp_cost[-1]), renorm=getattr(opt, 'l1_renorm', False))
+            if cost != 0:
+                raise NotImplementedError('a generator with get_comp_cost: the cost term has no kernel path')
+            self.loss_G_comp_cost = 0.0 * opt.lambda_comp_cost
         self.backward_terms([(opt.lambda_gan, gan), (opt.lambda_recon, recon)])
 
     def optimize_parameters(self, steps):
