@@ -77,7 +77,7 @@ def test_pix2pix_step_gpu():
     from cat_amd.models import create_model
     g = H.load('train_steps.npz')
     meta = json.loads(str(g['p2p_meta']))
-    opt = _opt_for(meta, model='pix2pix', lambda_recon=meta['lambda_recon'], lambda_gan=1.0, recon_loss_type='l1', lambda_comp_cost=0)
+    opt = _opt_for(meta, model='pix2pix', lambda_recon=meta['lambda_recon'], lambda_gan=1.0, recon_loss_type='l1', lambda_comp_cost=0.5, comp_cost='l1', l1_renorm=False)     # the comp-cost flag adds a zero term (pix2pix_model.py:186-195)
     m = create_model(opt, verbose=False)
     m.netG.load_state_dict(detfill.fill_state_dict(H.sd_from_shapes(g['p2p_G_shapes']), 301))
     m.netD.load_state_dict(detfill.fill_state_dict(H.sd_from_shapes(g['p2p_D_shapes']), 302))
@@ -92,6 +92,7 @@ def test_pix2pix_step_gpu():
             got = losses[('D_loss/' if k.startswith('D') else 'G_loss/') + k]
             ref = float(g[f'p2p_loss{step}:{k}'])
             assert abs(got - ref) <= 1e-3 * max(1.0, abs(ref)), (step, k, got, ref)
+        assert losses['G_loss/G_comp_cost'] == 0.0
         assert H.rel_err(H.sub(m.fake_B, 3, 4), g[f'p2p_fake{step}']) < (1e-3 if step == 0 else 1e-2)
         for key in g.files:
             if key.startswith(f'p2p_G{step}:') or key.startswith(f'p2p_D{step}:'):
