@@ -331,11 +331,9 @@ int cat_dwm_fwd(const cat_dwm_t* g, const float* x, const float* scale, const fl
   }
   const int cs = g->nq * 4;
   const size_t lds = (size_t)((TH + 4) * (TW + 4) * cs + 25 * cs + 4 * cs) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)dwm_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    attr_set = true;
-  }
+  CAT_REQUIRE(lds <= 96 * 1024, "dwm: %zu bytes of LDS (max 96 KB)", lds);
+  static cat::LdsOptIn optin;
+  cat::lds_optin(optin, (const void*)dwm_fwd_kernel, 96 * 1024);
   double taps = 0.0;
   for (int q = 0; q < g->nq; ++q) taps += 4.0 * g->ks[q] * g->ks[q];
   cat::ProfScope prof("dwconv_fwd", 2.0 * (double)g->N * g->H * g->W * taps, 0.0, stream);
@@ -582,11 +580,9 @@ int cat_dwm_bwd(const cat_dwm_t* g, const float* a, const float* dz, const float
   }
   const int cs = g->nq * 4, ntiles = g->N * p.tiles;
   const size_t lds = (size_t)(2 * (TH + 4) * (TW + 4) * cs + 25 * cs) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)dwm_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    attr_set = true;
-  }
+  CAT_REQUIRE(lds <= 144 * 1024, "dwm bwd: %zu bytes of LDS (max 144 KB)", lds);
+  static cat::LdsOptIn optin;
+  cat::lds_optin(optin, (const void*)dwm_bwd_kernel, 144 * 1024);
   hipStream_t s = (hipStream_t)stream;
   cat::ProfScope prof("dwconv_bwd", 4.0 * (double)g->N * g->H * g->W * taps, 0.0, stream);
   dwm_bwd_kernel<<<ntiles, 256, lds, s>>>(p);

@@ -47,6 +47,19 @@ bool twgrad_applicable(const cat_conv_t* g);
 int twgrad_nblk(const cat_conv_t* g);
 int twgrad(const cat_conv_t* g, const float* x, const float* dy, float* ws, hipStream_t s);   // partials [nblk][Cout][taps * round_up(Cin, 4)]
 
+// Opt a kernel in to more than 64 KB of dynamic LDS.  hipFuncSetAttribute applies to the CURRENT device only, so the "already
+// done" flag of a call site is kept per device ordinal (a process may drive several GPUs, e.g. the 2-ranks-on-one-box tests).
+struct LdsOptIn {
+  unsigned long long done = 0ull;
+};
+static inline void lds_optin(LdsOptIn& st, const void* fn, int bytes) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev >= 0 && dev < 64 && ((st.done >> dev) & 1ull)) return;
+  (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (dev >= 0 && dev < 64) st.done |= 1ull << dev;
+}
+
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 

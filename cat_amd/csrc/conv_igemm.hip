@@ -1812,11 +1812,8 @@ static int conv_fwd_impl(const cat_conv_t* g, const float* x, const float* w, co
                         stream);                                                                      \
     const dim3 grid(cdiv(a.M, WM * MT * 16) * cdiv(a.Cout, WN * NT * 16), a.ksplit);                   \
     const size_t lds = (size_t)2 * (WM * MT * 16 + WN * NT * 16) * 32 * sizeof(float);                \
-    static bool attr_set = false;                                                                     \
-    if (!attr_set) {                                                                                  \
-      (void)hipFuncSetAttribute((const void*)conv_fwd32_kernel<MT, NT, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-      attr_set = true;                                                                                \
-    }                                                                                                 \
+    static cat::LdsOptIn optin;                                                                       \
+    cat::lds_optin(optin, (const void*)conv_fwd32_kernel<MT, NT, WM, WN>, (int)lds);                  \
     conv_fwd32_kernel<MT, NT, WM, WN><<<grid, 256, lds, s>>>(a);                                       \
     if (a.ksplit > 1)                                                                                 \
       splitk_reduce_kernel<<<reduce_grid((int64_t)a.M * ((a.cw + 3) / 4)), 256, 0, s>>>(a.part, a.bias, a.out, a.M, a.Cout, a.cw, a.ycs,   \
@@ -1829,11 +1826,8 @@ static int conv_fwd_impl(const cat_conv_t* g, const float* x, const float* w, co
     cat::ProfScope prof("conv_fwd32d_4x4x2x2", prof_flops, 0.0, stream);
     const int grid = cdiv(a.M, 128) * cdiv(a.Cout, 128);
     const size_t lds = (size_t)2 * (128 + 128) * 32 * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)conv_fwd32d_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      attr_set = true;
-    }
+    static cat::LdsOptIn optin;
+    cat::lds_optin(optin, (const void*)conv_fwd32d_kernel<2>, (int)lds);
     conv_fwd32d_kernel<2><<<grid, 256, lds, s>>>(a);
     return cat::check_launch("conv2d_fwd");
   }
@@ -1960,12 +1954,9 @@ static int conv_dgrad_impl(const cat_conv_t* g, const float* dy, const float* w,
     cat::ProfScope prof(wt ? "conv_dgrad32dt_4x4x2x2" : "conv_dgrad32d_4x4x2x2", prof_flops, 0.0, stream);
     const dim3 grid(cdiv(mmax, 128) * cdiv(a.Cin, 128), st * st);
     const size_t lds = (size_t)2 * (128 + 128) * 32 * sizeof(float);
-    static bool attr_set_d = false;
-    if (!attr_set_d) {
-      (void)hipFuncSetAttribute((const void*)conv_dgrad32d_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      (void)hipFuncSetAttribute((const void*)conv_dgrad32d_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      attr_set_d = true;
-    }
+    static cat::LdsOptIn optin_d, optin_dt;
+    cat::lds_optin(optin_d, (const void*)conv_dgrad32d_kernel<false>, (int)lds);
+    cat::lds_optin(optin_dt, (const void*)conv_dgrad32d_kernel<true>, (int)lds);
     if (wt) conv_dgrad32d_kernel<true><<<grid, 256, lds, s>>>(a);
     else conv_dgrad32d_kernel<false><<<grid, 256, lds, s>>>(a);
     return cat::check_launch("conv2d_dgrad");
@@ -1974,11 +1965,8 @@ static int conv_dgrad_impl(const cat_conv_t* g, const float* dy, const float* w,
     cat::ProfScope prof("conv_dgrad32_4x4x2x2", prof_flops, 0.0, stream);
     const dim3 grid(cdiv(mmax, 128) * cdiv(a.Cin, 128), st * st);
     const size_t lds = (size_t)2 * (128 + 128) * 32 * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)conv_dgrad32_kernel<4, 4, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      attr_set = true;
-    }
+    static cat::LdsOptIn optin;
+    cat::lds_optin(optin, (const void*)conv_dgrad32_kernel<4, 4, 2, 2>, (int)lds);
     conv_dgrad32_kernel<4, 4, 2, 2><<<grid, 256, lds, s>>>(a);
     return cat::check_launch("conv2d_dgrad");
   }
@@ -2061,11 +2049,8 @@ int cat_conv2d_wgrad(const cat_conv_t* g, const float* x, const float* dy, float
       cat::ProfScope prof("conv_wgrad32d_4x4x2x2", prof_flops, 0.0, stream);
       const dim3 grid(cdiv(a.Cout, 128) * (a.K / 128), nsd);
       const size_t lds = (size_t)2 * 2 * 32 * 128 * sizeof(float);
-      static bool attr_set_w = false;
-      if (!attr_set_w) {
-        (void)hipFuncSetAttribute((const void*)conv_wgrad32d_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set_w = true;
-      }
+      static cat::LdsOptIn optin_w;
+      cat::lds_optin(optin_w, (const void*)conv_wgrad32d_kernel<2>, (int)lds);
       conv_wgrad32d_kernel<2><<<grid, 256, lds, s>>>(a, rows_per, cdiv(g->Wo, 32));
     }
     if (int e = cat::check_launch("conv2d_wgrad")) return e;

@@ -665,15 +665,13 @@ int cat_tconv_fwd(const cat_tconv_t* g, const float* pack, const float* bias, fl
   CAT_REQUIRE(grid < (int64_t)2147483647, "tconv: grid too large");
   const size_t lds = (size_t)2 * L.tr * L.tc * cat_pk::PITCH * sizeof(float) + 2 * cat_pk::TABN * sizeof(int) +
                      (g->stats ? (size_t)8 * nt * 16 * sizeof(float) : 0);
+  CAT_REQUIRE(lds <= 96 * 1024, "tconv: %zu bytes of LDS (max 96 KB)", lds);
   hipStream_t s = (hipStream_t)stream;
   cat::ProfScope prof(g->nseg > 1 ? "conv_tconv_multi" : "conv_tconv", 2.0 * (double)g->N * g->Ho * g->Wo * (g->nvalid > 0 ? g->nvalid : g->Nn) * kflops, 0.0, stream);
 #define CAT_PK_LAUNCH(NT, TW)                                                                                              \
   {                                                                                                                        \
-    static bool attr_set = false;                                                                                          \
-    if (!attr_set) {                                                                                                       \
-      (void)hipFuncSetAttribute((const void*)cat_pk::tconv_kernel<NT, TW>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \
-      attr_set = true;                                                                                                     \
-    }                                                                                                                      \
+    static cat::LdsOptIn optin;                                                                                            \
+    cat::lds_optin(optin, (const void*)cat_pk::tconv_kernel<NT, TW>, 96 * 1024);                                           \
     cat_pk::tconv_kernel<NT, TW><<<(int)grid, 256, lds, s>>>(*g, pack, bias, y, L);                                        \
   }
 #define CAT_PK_NT(TW)                          \

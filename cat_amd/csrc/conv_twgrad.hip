@@ -228,11 +228,8 @@ static int tw_launch(const cat_tw::Args& a, int nblk, hipStream_t s) {
   constexpr int PH = 8 + KS - 1;
   constexpr int XIT = (PH * PH * (cat_tw::pitch_of(PT) / 4) + 255) / 256, YIT = (64 * (cat_tw::pitch_of(QT) / 4) + 255) / 256;
   const size_t lds = (size_t)2 * (XIT + YIT) * 1024 * sizeof(float);      // two buffers of whole 1 KB DMA rows
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)cat_tw::twgrad_kernel<PT, QT, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr = true;
-  }
+  static cat::LdsOptIn optin;
+  cat::lds_optin(optin, (const void*)cat_tw::twgrad_kernel<PT, QT, KS>, (int)lds);
   cat_tw::twgrad_kernel<PT, QT, KS><<<nblk, 256, lds, s>>>(a);
   return check_launch("conv2d_twgrad");
 }

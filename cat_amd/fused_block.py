@@ -249,6 +249,7 @@ class _Plan:
             fwd.append(vec(self.bias2, 0, b2, self.C))
         self.ptrs = tuple(p.data_ptr() for p in self.block.parameters())
         self.shapes = tuple(tuple(p.shape) for p in self.block.parameters())
+        self.ids = tuple(id(p) for p in self.block.parameters())
         self.fwd_jobs = self._jobs_to_dev(fwd)
         self.bwd_jobs = self._jobs_to_dev(bwd)
 
@@ -277,7 +278,10 @@ class _Plan:
 
 def plan_for(block, x):
     p = getattr(block, '_cat_fused_plan', None)
-    if p is None or p.dev != x.device or p.shapes != tuple(tuple(q.shape) for q in block.parameters()):
+    # the plan holds Parameter OBJECTS (gradient targets are keyed by identity): a parameter replaced by one of the same shape
+    # (module.weight = nn.Parameter(...), weight transfer) invalidates it like a shape change does
+    if p is None or p.dev != x.device or p.shapes != tuple(tuple(q.shape) for q in block.parameters()) or \
+            p.ids != tuple(id(q) for q in block.parameters()):
         p = _Plan(block, x.device)
         block._cat_fused_plan = p
     return p
@@ -425,9 +429,7 @@ class _BlockFn(torch.autograd.Function):
         grads = {}
         pad_mode = L.PAD_REFLECT if p.reflect else L.PAD_ZERO
 
-        side = ops.SideJobs(dev)
-        keep = []      # temporaries read by side-stream launches stay referenced until side.join(): freed earlier, the caching allocator
-        #                would hand their memory to the next main-stream kernel while a side stream still reads it
+        side = ops.SideJobs(dev)      # the temporaries its launches read (a1, ad, dt, dz1) stay referenced by this frame until side.join()
 
         def put(param, kernel):
             grads[id(param)] = ops._write_param_grad(param, kernel)
@@ -586,7 +588,6 @@ class _BlockFn(torch.autograd.Function):
             else:
                 tconv.run(segs, p.dpack1, None, dx, c, n, h, w, h, w, res=dy)
         side.join()
-        del keep
         # ---- 9. scatter the concatenated parameter gradients
         all_t = [q for _, _, _, q in p.targets] + [t2[5] for t2 in p.targets2d]
         owned = [getattr(q, '_cat_grad_view', None) is not None for q in all_t]

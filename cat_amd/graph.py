@@ -37,6 +37,27 @@ class GraphedStep:
             model.set_input(self.static)
             model.optimize_parameters(warmup)
         self.replays = 0
+        # the graph's outputs are the tensors the model's attributes were bound to DURING the capture (loss terms, fake images, input
+        # fields, tapped activations).  An eager fallback step rebinds those attributes to fresh tensors; the bindings are restored before
+        # the next replay's results are read, otherwise get_current_losses() / get_current_visuals() would keep returning the values of
+        # that one eager step
+        self._bound = self._graph_bindings()
+        self._stale = False
+
+    def _graph_bindings(self):
+        m = self.model
+        names = set(getattr(m, 'visual_names', [])) | {'real_A', 'real_B', 'input_semantics', 'Sfake_B', 'Tfake_B', 'loss_G', 'loss_D'}
+        bound = {k: v for k, v in vars(m).items() if k.startswith('loss_') or k in names}
+        taps = {k: dict(getattr(m, k)) for k in ('Sacts', 'Tacts') if isinstance(getattr(m, k, None), dict)}
+        return bound, taps
+
+    def _rebind(self):
+        bound, taps = self._bound
+        for k, v in bound.items():
+            setattr(self.model, k, v)
+        for k, d in taps.items():
+            getattr(self.model, k).update(d)
+        self._stale = False
 
     def __call__(self, batch):
         for k, v in batch.items():
@@ -44,6 +65,7 @@ class GraphedStep:
                 # e.g. the smaller last batch of an epoch: shapes are baked into the capture -> run this step eagerly
                 self.model.set_input(batch)
                 self.model.optimize_parameters(self.replays)
+                self._stale = True
                 return
         for k, v in batch.items():
             if torch.is_tensor(v):
@@ -54,6 +76,8 @@ class GraphedStep:
             if hasattr(opt, 'sync_hyper_for_replay'):
                 opt.sync_hyper_for_replay()
         self.graph.replay()
+        if self._stale:
+            self._rebind()
         # host-side field set_input would have refreshed (base_inception_distiller.py set_input: A_paths / B_paths / path)
         opt_ = getattr(self.model, 'opt', None)
         key = 'A_paths' if getattr(opt_, 'direction', 'AtoB') == 'AtoB' else 'B_paths'

@@ -313,10 +313,14 @@ def set_tconv_min_tiles(n):
     return old
 
 
-def tconv_applicable(n, h, w, cout, kh, kw, stride, pad):
+def tconv_applicable(n, h, w, cout, kh, kw, stride, pad, cin=None):
     """Stride-1 "same" 3x3 / 5x5 convolutions with enough output tiles to fill the chip go through csrc/conv_pk.hip (forward and
-    input gradient); tiny planes (the SPADE generators' 4x8 .. 16x32 stages) keep the split-K im2col kernels, Cout <= 3 the direct ones."""
+    input gradient); tiny planes (the SPADE generators' 4x8 .. 16x32 stages) keep the split-K im2col kernels, Cout <= 3 the direct ones.
+    Wide layers the direct-to-LDS 128 x 128 x 32 GEMM tiles accept (reduction channels % 32 == 0, more than 96 output channels: e.g. the
+    256 -> 256 3x3 convs of a resnet generator) stay on those: their matrix pipe runs 0.9 busy against 0.75-0.8 for the LDS-tile kernel."""
     if not _TCONV or stride != 1 or kh != kw or kh not in (3, 5) or pad != (kh - 1) // 2 or cout <= 3:
+        return False
+    if cin is not None and cin % 32 == 0 and cout > 96:
         return False
     return n * ((h + 7) // 8) * ((w + 15) // 16) >= _TCONV_MIN_TILES
 
@@ -401,7 +405,7 @@ class Conv2dFn(torch.autograd.Function):
         ho = (h + 2 * pad - kh) // stride + 1
         wo = (w + 2 * pad - kw) // stride + 1
         y = empty_act(n, cout, ho, wo, x.device)
-        if tconv_applicable(n, h, w, cout, kh, kw, stride, pad):
+        if tconv_applicable(n, h, w, cout, kh, kw, stride, pad, cin):
             from . import tconv
             pk = packed_filter(weight, wcl, tconv.FWD)
             tconv.run([tconv.Segment(x, kh, pad, pad_mode == L.PAD_REFLECT, 0)], pk, bias, y, cout, n, h, w, ho, wo, act, slope)
@@ -425,7 +429,7 @@ class Conv2dFn(torch.autograd.Function):
         st = _stream()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            tile = tconv_applicable(n, h, w, cin, kh, kw, stride, pad)
+            tile = tconv_applicable(n, h, w, cin, kh, kw, stride, pad, cout)
             if tile:
                 from . import tconv
                 pk = packed_filter(ctx.weight, wcl, tconv.DGRAD)

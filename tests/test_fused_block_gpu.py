@@ -128,3 +128,28 @@ def test_fused_block_backward_matches_torch(norm, padding, shape):
         if err > 5e-4:
             bad[k] = err
     assert not bad, bad
+
+
+def test_fused_block_plan_follows_replaced_parameters():
+    """A parameter object replaced by a new one of the same shape (weight transfer, `m.weight = nn.Parameter(...)`) must receive its
+    gradient: the cached plan keys gradient targets by parameter identity and is rebuilt when the identities change."""
+    from cat_amd import _lib, fused_block, ops
+    _lib.load()
+    dev = torch.device('cuda:0')
+    blk = _block('batch', dev)
+    x = ops.to_nhwc(detfill.normal((4, 77, 48, 64), 5).to(dev))
+    gy = ops.to_nhwc(detfill.normal((4, 77, 48, 64), 6).to(dev))
+    xg = x.detach().requires_grad_(True)
+    blk(xg).backward(gy)
+    old = blk.res_ops[0][1][1].weight
+    g_old = old.grad.clone()
+    blk.res_ops[0][1][1].weight = torch.nn.Parameter(old.detach().clone())
+    blk.pw_bn.bias = torch.nn.Parameter(blk.pw_bn.bias.detach().clone())
+    blk.zero_grad()
+    xg = x.detach().requires_grad_(True)
+    assert fused_block.applicable(blk, xg)
+    blk(xg).backward(gy)
+    torch.cuda.synchronize()
+    new = blk.res_ops[0][1][1].weight
+    assert new.grad is not None and blk.pw_bn.bias.grad is not None
+    assert rel(new.grad, g_old) < 1e-4      # (running statistics moved between the two steps: batch statistics did not)

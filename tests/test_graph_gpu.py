@@ -65,6 +65,19 @@ def test_graph_replay_equals_eager_inception():
     small = {k: (v[:1] if torch.is_tensor(v) else v) for k, v in batches[1].items()}
     step(small)
     assert graphed.Sfake_B.shape[0] == 1
+    # ... and the replay that follows reports ITS losses / images again (the fallback rebinds loss_* / Sfake_B to eager tensors)
+    small_losses = graphed.get_current_losses()
+    eager.set_input(small)
+    eager.optimize_parameters(8)
+    eager.set_input(batches[1])
+    eager.optimize_parameters(9)
+    step(batches[1])
+    assert graphed.Sfake_B.shape[0] == n
+    le, lg = eager.get_current_losses(), graphed.get_current_losses()
+    assert any(abs(lg[k] - small_losses[k]) > 1e-7 for k in lg), 'losses frozen at the eager fallback step'
+    for k in le:
+        assert abs(le[k] - lg[k]) <= 1e-5 * max(1.0, abs(le[k])), (k, le[k], lg[k])
+    assert float((graphed.Sfake_B - eager.Sfake_B).abs().max()) < 1e-5
 
 
 def test_graph_replay_equals_eager_spade():
