@@ -27,13 +27,17 @@ import torch  # noqa: E402
 MFMA_F32_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 256 CUs @ 2.4 GHz
 
 
+C2 = dict(norm='batch', track=True, ndf=128, dataset_mode='aligned', gan_mode='hinge', lambda_recon=100.0, lambda_distill=1.3)
+C3 = dict(norm='instance', track=False, ndf=64, dataset_mode='unaligned', gan_mode='lsgan', lambda_recon=5.0, lambda_distill=1.0)
+
+
 def build_model(args, device_index):
-    """BASELINE configs[1]: canonical teacher, student pruned from it, PatchGAN, both optimizers."""
+    """BASELINE configs[1]: canonical teacher, student pruned from it, PatchGAN, both optimizers.
+    `--workload c3` = configs[2] per GPU: CycleGAN-style distillation (InstanceNorm, lsgan, unaligned, ndf 64, student S_2.6)."""
     from cat_amd import networks, prune, synthetic
     from cat_amd.distillers import create_distiller
-    opt = synthetic.default_options(norm='batch', track=True, ndf=128, dataset_mode='aligned', gan_mode='hinge', lambda_recon=100.0,
-                                    lambda_distill=1.3, target_flops=args.target_flops, prune_cin_lb=16, student_ngf=32,
-                                    gpu_ids=[device_index], data_height=args.size, data_width=args.size)
+    opt = synthetic.default_options(**(C3 if getattr(args, 'workload', 'c2') == 'c3' else C2), target_flops=args.target_flops, prune_cin_lb=16,
+                                    student_ngf=32, gpu_ids=[device_index], data_height=args.size, data_width=args.size)
     torch.manual_seed(233)
     model = create_distiller(opt, verbose=False)
     # canonical teacher: deterministic weights, |N(0,1)| norm scales (a trained teacher's scales are non-uniform)
@@ -112,38 +116,69 @@ def cpu_baseline_spade(opt, model, args):
     ins = torch.from_numpy(np.repeat(np.repeat(rng.integers(0, 1000, (1, 1, h // 16, w // 16)), 16, 2), 16, 3).astype(np.int32))
     sem = R.preprocess_input(lab, ins, 35)
     img = detfill.images((1, 3, h, w), 6)
-    cores = torch.get_num_threads()
-    t0 = time.perf_counter()
-    R.spade_step(st, sem, img)
-    dt = time.perf_counter() - t0
+    was = torch.get_num_threads()
+    cores = physical_cores()
+    torch.set_num_threads(cores)
+    try:
+        R.spade_step(st, sem, img)
+        times = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            R.spade_step(st, sem, img)
+            times.append(time.perf_counter() - t0)
+    finally:
+        torch.set_num_threads(was)
+    dt = sorted(times)[1]
     return {'value': round(1 / dt, 4), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
-            'sample': f'oracle/ref_spade_cpu.spade_step, batch 1 @ {w}x{h}, ONE timed step (no warm-up: ~20-40 s of host work), '
-                      f'{cores} torch threads'}
+            'sample': f'oracle/ref_spade_cpu.spade_step, batch 1 @ {w}x{h}, 1 warm-up + median of 3 timed steps ({min(times):.1f}-{max(times):.1f} s), '
+                      f'torch.set_num_threads({cores}) = physical cores of {os.cpu_count()} logical'}
+
+
+def physical_cores():
+    """Physical cores of the host (time the CPU path on all PHYSICAL cores; 2 x SMT threads oversubscribe ATen's pools:
+    the same port ran 0.30 images/s on 128 threads and 0.84 on 8)."""
+    try:
+        import psutil
+        n = psutil.cpu_count(logical=False)
+        if n:
+            return int(n)
+    except Exception:      # noqa: BLE001
+        pass
+    return max(1, (os.cpu_count() or 2) // 2)
+
+
+def oracle_cfg(opt):
+    ncfg = {'norm': opt.norm, 'eps': opt.norm_epsilon, 'momentum': opt.norm_momentum}
+    return dict(T=ncfg, S=ncfg, D=ncfg, dataset_mode=opt.dataset_mode, gan_mode=opt.gan_mode, lambda_recon=opt.lambda_recon,
+                lambda_distill=opt.lambda_distill, lambda_gan=1.0, lr=opt.lr, beta1=opt.beta1)
 
 
 def cpu_baseline(opt, model, args):
-    """The CPU oracle (a port: plain PyTorch ATen ops, same algorithm) on a bounded sample: batch 2 at the bench
-    resolution, 1 warm-up + the median of 3 timed steps (~20-30 s of host work; SURVEY §8d's batch 4 / median of 5 would take minutes)."""
+    """The CPU oracle (a port: plain PyTorch ATen ops, same algorithm) on a bounded sample with SURVEY §8d's protocol: all physical
+    cores, batch 4 at the bench resolution, 2 warm-up steps + the median of 5 timed steps (`--cpu-baseline-quick`: batch 2, 1 + 3)."""
     from oracle import detfill, ref_cpu
-    nb = 2
-    ncfg = {'norm': 'batch', 'eps': opt.norm_epsilon, 'momentum': opt.norm_momentum}
-    cfg = dict(T=ncfg, S=ncfg, D=ncfg, dataset_mode='aligned', gan_mode='hinge', lambda_recon=100.0, lambda_distill=1.3, lambda_gan=1.0,
-               lr=opt.lr, beta1=opt.beta1)
+    nb, warm, reps = (2, 1, 3) if args.cpu_baseline_quick else (4, 2, 5)
     cpu = lambda net: {k: v.detach().cpu().contiguous().clone() for k, v in net.state_dict().items()}
-    st = ref_cpu.DistillState(cpu(model.netG_teacher), cpu(model.netG_student), cpu(model.netD), cfg)
-    cores = torch.get_num_threads()
-    A = detfill.images((nb, 3, args.size, args.size), 1)
-    B = detfill.images((nb, 3, args.size, args.size), 2)
-    ref_cpu.distill_step(st, A, B)
-    reps, times = 3, []
-    for _ in range(reps):
-        t0 = time.perf_counter()
-        ref_cpu.distill_step(st, A, B)
-        times.append(time.perf_counter() - t0)
+    st = ref_cpu.DistillState(cpu(model.netG_teacher), cpu(model.netG_student), cpu(model.netD), oracle_cfg(opt))
+    was = torch.get_num_threads()
+    cores = physical_cores()
+    torch.set_num_threads(cores)
+    try:
+        A = detfill.images((nb, 3, args.size, args.size), 1)
+        B = detfill.images((nb, 3, args.size, args.size), 2)
+        for _ in range(warm):
+            ref_cpu.distill_step(st, A, B)
+        times = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            ref_cpu.distill_step(st, A, B)
+            times.append(time.perf_counter() - t0)
+    finally:
+        torch.set_num_threads(was)
     dt = sorted(times)[reps // 2]
     return {'value': round(nb / dt, 4), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
-            'sample': f'oracle/ref_cpu.distill_step, batch {nb} @ {args.size}x{args.size}, 1 warm-up + median of {reps} timed steps '
-                      f'({min(times):.2f}-{max(times):.2f} s), {cores} torch threads'}
+            'sample': f'oracle/ref_cpu.distill_step, batch {nb} @ {args.size}x{args.size}, {warm} warm-up + median of {reps} timed steps '
+                      f'({min(times):.2f}-{max(times):.2f} s), torch.set_num_threads({cores}) = physical cores of {os.cpu_count()} logical'}
 
 
 def main():
@@ -152,17 +187,24 @@ def main():
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--sustained-steps', type=int, default=100, help='extra steps after the timed region (N=1): the clock-settled rate')
-    ap.add_argument('--workload', default='c2', choices=['c2', 'spade'],
-                    help='c2 = pix2pix InceptionDistiller (BASELINE configs[1], the headline metric); spade = GauGAN SPADEDistiller '
+    ap.add_argument('--workload', default='c2', choices=['c2', 'c3', 'spade'],
+                    help='c2 = pix2pix InceptionDistiller (BASELINE configs[1], the headline metric); c3 = CycleGAN-style InceptionDistiller '
+                         '(configs[2] per GPU: InstanceNorm, lsgan, unaligned, ndf 64, batch 8); spade = GauGAN SPADEDistiller '
                          '(configs[3], per-GPU batch 4 @ 512x256)')
-    ap.add_argument('--batch', type=int, default=None, help='per-GPU batch (default: 16 for c2, 4 for spade)')
+    ap.add_argument('--batch', type=int, default=None, help='per-GPU batch (default: 16 for c2, 8 for c3, 4 for spade)')
+    ap.add_argument('--cpu-baseline-quick', action='store_true', dest='cpu_baseline_quick',
+                    help='cpu_baseline on batch 2, 1 warm-up + median of 3 (default: SURVEY §8d protocol, batch 4, 2 + 5)')
     ap.add_argument('--size', type=int, default=256, help='image height (spade: width = 2 * size)')
     ap.add_argument('--target-flops', type=float, default=None, dest='target_flops')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-profile', action='store_true')
     ap.add_argument('--no-overlap', action='store_true')
     ap.add_argument('--teacher-side-stream', type=int, default=0, help='c2: run the frozen teacher forward on a side stream (1 GPU)')
-    ap.add_argument('--graph', type=int, default=1, help='1 (default): replay the step as one captured hipGraph on 1 GPU; 0: eager launches')
+    ap.add_argument('--graph', type=int, default=1, help='1 (default): replay the captured step (one hipGraph on 1 GPU; hipGraph segments around '
+                                                         'the two collectives with N > 1 ranks, c2 only); 0: eager launches')
+    ap.add_argument('--dp-schedule', type=int, default=0, dest='dp_schedule',
+                    help='1 GPU only: run the DATA-PARALLEL schedule through a world_size-1 RCCL group (same launch mode as the N > 1 points '
+                         'of a scaling curve: teacher on a side stream, bucket all-reduces, deferred Adam G)')
     args = ap.parse_args()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         # `python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run (one rank per GPU, RCCL over xGMI);
@@ -183,13 +225,15 @@ def main():
     sys.stdout = sys.stderr
     spade = args.workload == 'spade'
     if args.batch is None:
-        args.batch = 4 if spade else 16
+        args.batch = 4 if spade else (8 if args.workload == 'c3' else 16)
     if args.target_flops is None:
-        args.target_flops = 5.6e9 if spade else 4.6e9
+        args.target_flops = 5.6e9 if spade else (2.6e9 if args.workload == 'c3' else 4.6e9)
 
     from cat_amd import _lib, ops, parallel
     _lib.load()
     rank, world, local = parallel.init_distributed()
+    if world == 1 and args.dp_schedule:
+        parallel.init_single_rank_group()
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}')
     if not torch.cuda.is_available():
@@ -202,7 +246,8 @@ def main():
         model.teacher_side_stream = False
     elif args.teacher_side_stream and not spade:
         model.teacher_side_stream = True
-    if world > 1:
+    dp = world > 1 or bool(args.dp_schedule)
+    if dp:
         if spade:
             model.enable_data_parallel(parallel.DataParallelReducer())
         else:
@@ -224,11 +269,14 @@ def main():
 
     step = eager_step
     graphed = None
-    if args.graph and world == 1 and not getattr(model, 'teacher_side_stream', False):
-        from cat_amd.graph import GraphedStep
+    launch = 'eager'
+    if args.graph and (dp and not spade and not args.no_overlap or not dp and not getattr(model, 'teacher_side_stream', False)):
+        from cat_amd.graph import GraphedDPStep, GraphedStep
         try:
-            graphed = GraphedStep(model, batches[0])
+            graphed = (GraphedDPStep if dp else GraphedStep)(model, batches[0])
+            launch = 'hipGraph segments around the collectives (teacher | student fwd + D bwd | Adam D + G bwd)' if dp else 'hipGraph replay'
         except Exception as e:      # a failed capture must not cost the measurement: fall back to eager launches and say so
+            # (deterministic across ranks: every rank captures the same launch sequence, so all of them fall back together)
             print(f'[bench] hipGraph capture failed ({type(e).__name__}: {e}); timing eager launches', file=sys.stderr, flush=True)
             graphed = None
             torch.cuda.synchronize()
@@ -247,7 +295,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
-    if world > 1 and hasattr(model, 'finish_pending'):
+    if dp and hasattr(model, 'finish_pending'):
         model.finish_pending()
     barrier()
     dt = time.perf_counter() - t0
@@ -275,7 +323,7 @@ def main():
     roofline = student_fwd = None
     if not args.no_kernel_profile and (rank == 0 or world > 1):
         roofline = kernel_roofline(model, eager_step, args)
-        if world > 1 and hasattr(model, 'finish_pending'):
+        if dp and hasattr(model, 'finish_pending'):
             model.finish_pending()
         student_fwd = student_forward_rate(model, batches[0], spade, graph=world == 1)
     if world > 1:
@@ -288,8 +336,12 @@ def main():
         image, n_macs = f'{2 * args.size}x{args.size}', int(model.modules_on_one_gpu.netG_student.n_macs)
     else:
         metric = f'distill-step images/sec @{args.size}x{args.size} bs={args.batch}'      # default: BASELINE.json's @256x256 bs=16
-        workload = ('pix2pix InceptionDistiller.optimize_parameters (BASELINE configs[1]): teacher ngf64 frozen + student '
-                    f'pruned to {args.target_flops:.2g} MACs + PatchGAN ndf128, hinge + L1 + KA, Adam x2')
+        if args.workload == 'c3':
+            workload = ('CycleGAN-style InceptionDistiller.optimize_parameters (BASELINE configs[2], per GPU): teacher ngf64 frozen + student '
+                        f'pruned to {args.target_flops:.2g} MACs + PatchGAN ndf64, InstanceNorm, lsgan + L1(teacher) + KA, Adam x2')
+        else:
+            workload = ('pix2pix InceptionDistiller.optimize_parameters (BASELINE configs[1]): teacher ngf64 frozen + student '
+                        f'pruned to {args.target_flops:.2g} MACs + PatchGAN ndf128, hinge + L1 + KA, Adam x2')
         image, n_macs = f'{args.size}x{args.size}', int(model.netG_student.n_macs)
     out = {
         'metric': metric, 'value': round(ips, 3), 'unit': 'images/sec', 'n_gpus': world,
@@ -297,8 +349,9 @@ def main():
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': workload, 'image': image, 'per_gpu_batch': args.batch, 'global_batch': args.batch * world,
                    'parallelism': f'dp{world}', 'ranks': world,
-                   'collectives': (f'{torch.distributed.get_backend()} all-reduce of the flat gradient buckets' if world > 1 else 'none'),
-                   'student_n_macs': n_macs, 'launch': 'hipGraph replay' if graphed is not None else 'eager'},
+                   'collectives': (f'{parallel.backend_version()} all-reduce of the flat gradient buckets' if dp else 'none'),
+                   'schedule': 'data-parallel' if dp else 'single-GPU',
+                   'student_n_macs': n_macs, 'launch': launch if graphed is not None else 'eager'},
         'roofline': roofline,
         'student_forward': student_fwd,
     }
@@ -308,7 +361,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = (cpu_baseline_spade if spade else cpu_baseline)(opt, model, args)
         print(json.dumps(out), file=json_out, flush=True)
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

@@ -175,25 +175,39 @@ class InceptionDistiller(BaseInceptionDistiller):
         """Same arithmetic as optimize_parameters, scheduled for xGMI overlap:
           side stream : frozen-teacher forward of THIS batch
           main stream : [wait G all-reduce of the previous step -> Adam G] -> student forward -> D step (D bucket
-                        all-reduce, Adam D) -> backward_G -> launch G bucket all-reduce (awaited next call)."""
+                        all-reduce, Adam D) -> backward_G -> launch G bucket all-reduce (awaited next call).
+        The three compute pieces (_dp_teacher / _dp_first / _dp_second) are what cat_amd.graph.GraphedDPStep captures as hipGraph
+        segments; the collectives and the one-launch Adam G between them stay eager."""
         main = torch.cuda.current_stream(self.device)
         side = self._side_stream
         side.wait_stream(main)
         self.real_A.record_stream(side)
-        with torch.cuda.stream(side), torch.no_grad():
-            self.Tfake_B = self.netG_teacher(self.real_A)
+        with torch.cuda.stream(side):
+            self._dp_teacher()
         t_done = side.record_event()
         self.finish_pending()
+        self._dp_first()
+        self.dp.reduce(self.optimizer_D)
+        main.wait_event(t_done)
+        for t in [self.Tfake_B] + list(self.Tacts.values()):
+            t.record_stream(main)
+        self._dp_second(steps)
+        self._pending_G = self.dp.reduce_async(self.optimizer_G)
+
+    def _dp_teacher(self):
+        with torch.no_grad():
+            self.Tfake_B = self.netG_teacher(self.real_A)
+
+    def _dp_first(self):
+        """Student forward + the discriminator's backward pass: everything up to the D-bucket all-reduce."""
         self.Sfake_B = self.netG_student(self.real_A)
         self.set_requires_grad(self.netD, True)
         self.optimizer_D.zero_grad()
         self.backward_D()
-        self.dp.reduce(self.optimizer_D)
+
+    def _dp_second(self, steps):
+        """Adam D on the reduced bucket + the generator's backward pass: everything up to the G-bucket all-reduce."""
         self.optimizer_D.step()
         self.set_requires_grad(self.netD, False)
         self.optimizer_G.zero_grad()
-        main.wait_event(t_done)
-        for t in [self.Tfake_B] + list(self.Tacts.values()):
-            t.record_stream(main)
         self.backward_G(steps)
-        self._pending_G = self.dp.reduce_async(self.optimizer_G)

@@ -87,3 +87,91 @@ class GraphedStep:
         for opt in self.model.optimizers:
             opt.note_graph_replay()
         self.replays += 1
+
+
+class GraphedDPStep:
+    """The data-parallel InceptionDistiller step (InceptionDistiller._optimize_parameters_dp) as hipGraph SEGMENTS around its two
+    collectives, so that the N-GPU job launches its kernels the way the one-GPU headline run does:
+
+        main : g_in  (set_input: layout kernels into static buffers)
+        side : g_T   (frozen-teacher forward of this batch -- overlaps the wait for the previous step's student all-reduce)
+        main : [wait G bucket of the previous step -> Adam G (one eager launch)] -> g_A (student forward, backward_D)
+               -> RCCL all-reduce of the D bucket -> join side -> g_B (Adam D, backward_G) -> async all-reduce of the G bucket
+
+    g_T has its own memory pool (it runs concurrently with g_A); g_A / g_B share one (the autograd tape of the student forward is
+    consumed by backward_G) and are always replayed in capture order.  Collectives are never captured: RCCL enqueues them between the
+    graph launches with ordinary stream ordering.  The SPADE step exchanges SynchronizedBatchNorm statistics inside its passes
+    (dozens of small collectives) and stays eager."""
+
+    def __init__(self, model, example_batch, warmup=3):
+        if getattr(model, 'dp', None) is None or not hasattr(model, '_dp_first'):
+            raise RuntimeError('GraphedDPStep: needs an InceptionDistiller with enable_data_parallel(...)')
+        self.model = model
+        dev = model.device
+        self.static = {k: (v.to(dev).clone() if torch.is_tensor(v) else v) for k, v in example_batch.items()}
+        cur = torch.cuda.current_stream()
+        warm = torch.cuda.Stream()
+        warm.wait_stream(cur)
+        with torch.cuda.stream(warm):
+            for i in range(warmup):          # eager DP steps (collectives included: every rank does the same)
+                model.set_input(self.static)
+                model.optimize_parameters(i)
+            model.finish_pending()
+        cur.wait_stream(warm)
+        torch.cuda.synchronize()
+        side = model._side_stream
+        kw = dict(capture_error_mode='thread_local')      # RCCL's watchdog thread may query events while this thread captures
+        self.g_in, self.g_T, self.g_A, self.g_B = (torch.cuda.CUDAGraph() for _ in range(4))
+        with torch.cuda.graph(self.g_in, **kw):
+            model.set_input(self.static)
+        with torch.cuda.graph(self.g_T, stream=side, **kw):
+            model._dp_teacher()
+        with torch.cuda.graph(self.g_A, **kw):
+            model._dp_first()
+        with torch.cuda.graph(self.g_B, pool=self.g_A.pool(), **kw):
+            model._dp_second(warmup)
+        torch.cuda.synchronize()
+        self._bound = GraphedStep._graph_bindings(self)
+        self._stale = False
+        self.replays = 0
+
+    _rebind = GraphedStep._rebind
+
+    def __call__(self, batch):
+        m = self.model
+        for k, v in batch.items():
+            if torch.is_tensor(v) and (k not in self.static or tuple(v.shape) != tuple(self.static[k].shape)):
+                m.set_input(batch)             # another shape (last batch of an epoch): this step runs eagerly on every rank
+                m.optimize_parameters(self.replays)
+                self._stale = True
+                return
+        for k, v in batch.items():
+            if torch.is_tensor(v):
+                self.static[k].copy_(v, non_blocking=True)
+            else:
+                self.static[k] = v
+        for opt in m.optimizers:
+            if hasattr(opt, 'sync_hyper_for_replay'):
+                opt.sync_hyper_for_replay()
+        main = torch.cuda.current_stream(m.device)
+        side = m._side_stream
+        self.g_in.replay()
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            self.g_T.replay()
+        t_done = side.record_event()
+        m.finish_pending()                      # wait for the previous step's G bucket, Adam G (eager: one launch)
+        self.g_A.replay()
+        m.dp.reduce(m.optimizer_D)
+        main.wait_event(t_done)
+        self.g_B.replay()
+        m.optimizer_D.note_graph_replay()       # Adam D ran inside g_B
+        m._pending_G = m.dp.reduce_async(m.optimizer_G)
+        if self._stale:
+            self._rebind()
+        opt_ = getattr(m, 'opt', None)
+        key = 'A_paths' if getattr(opt_, 'direction', 'AtoB') == 'AtoB' else 'B_paths'
+        paths = batch.get('path', batch.get(key))
+        if paths is not None:
+            m.image_paths = paths
+        self.replays += 1

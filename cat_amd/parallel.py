@@ -43,6 +43,38 @@ def init_distributed(backend=None):
     return rank, world, local
 
 
+def init_single_rank_group(backend=None, local=0):
+    """A world_size-1 process group on this GPU (backend 'nccl' = RCCL with one rank).  It lets a one-GPU box run the data-parallel
+    schedule end to end -- RCCL loaded, `device_id=` initialisation, all-reduce on the real flat gradient buckets, Work.wait() stream
+    ordering -- which is what `bench.py --dp-schedule 1` and tests/test_dp_gpu.py::test_single_rank_rccl_* exercise."""
+    if dist.is_initialized():
+        return 0, 1, local
+    import socket
+    backend = backend or os.environ.get('CAT_DIST_BACKEND') or 'nccl'
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    kw = {}
+    if backend == 'nccl':
+        torch.cuda.set_device(local)
+        kw['device_id'] = torch.device('cuda', local)
+    dist.init_process_group(backend=backend, init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1, **kw)
+    return 0, 1, local
+
+
+def backend_version():
+    """'rccl x.y.z' (torch.cuda.nccl.version() IS the RCCL version on ROCm) or the backend's name."""
+    if not dist.is_initialized():
+        return None
+    b = dist.get_backend()
+    if b == 'nccl':
+        try:
+            return 'rccl ' + '.'.join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:      # noqa: BLE001  (version query is informational only)
+            return 'rccl'
+    return b
+
+
 def shard_batch(batch, rank, world_size):
     """The chunk DataParallel.scatter would hand replica `rank` (contiguous split of dim 0, torch.chunk semantics)."""
     out = {}

@@ -129,10 +129,10 @@ def ka(X, Y):
 def gan_loss(gan_mode, prediction, target_is_real, for_discriminator=True):
     """GANLoss.__call__, models/modules/loss.py:52-99 (lsgan, vanilla, wgangp, hinge incl. the multiscale list form)."""
     if gan_mode == 'lsgan':
-        target = torch.tensor(1.0 if target_is_real else 0.0).expand_as(prediction)
+        target = torch.tensor(1.0 if target_is_real else 0.0, dtype=prediction.dtype).expand_as(prediction)
         return F.mse_loss(prediction, target)
     if gan_mode == 'vanilla':       # nn.BCEWithLogitsLoss, loss.py:33-34
-        target = torch.tensor(1.0 if target_is_real else 0.0).expand_as(prediction)
+        target = torch.tensor(1.0 if target_is_real else 0.0, dtype=prediction.dtype).expand_as(prediction)
         return F.binary_cross_entropy_with_logits(prediction, target)
     if gan_mode == 'wgangp':        # loss.py:66-70
         return -prediction.mean() if target_is_real else prediction.mean()

@@ -170,3 +170,76 @@ def test_spade_data_parallel_two_ranks():
         r = st.S[k].detach().reshape(-1)[:64].numpy()
         tol = 1e-3 * float(np.abs(r).max()) + (0 if 'running' in k else 2 * lr)
         assert float(np.abs(v - r).max()) <= tol, (k, float(np.abs(v - r).max()), tol)
+
+
+def _worker_single_rank_rccl(rank, world, port, q):
+    """world_size-1 RCCL group on the one GPU: the data-parallel schedule (eager and as hipGraph segments) against the plain step."""
+    os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    os.environ.pop('CAT_DIST_BACKEND', None)
+    from cat_amd import parallel
+    from cat_amd.graph import GraphedDPStep
+    parallel.init_single_rank_group('nccl')
+    assert torch.distributed.get_backend() == 'nccl' and torch.distributed.get_world_size() == 1
+    version = parallel.backend_version()
+    g = H.load('step_in.npz')
+    meta = json.loads(str(g['meta']))
+    opt = H.make_opt(norm=meta['norm'], track=meta['track'], ndf=meta['ndf'], dataset_mode=meta['dataset_mode'], gan_mode=meta['gan_mode'],
+                     lambda_recon=meta['lambda_recon'], lambda_distill=meta['lambda_distill'], student_ngf=16)
+    n, s = 2, meta['size']
+    batches = [{'A': detfill.images((n, 3, s, s), 830 + i).cuda(), 'B': detfill.images((n, 3, s, s), 840 + i).cuda(), 'A_paths': [], 'B_paths': []}
+               for i in range(4)]
+    order = [0, 0, 1, 2, 3]           # GraphedDPStep: 2 eager warm-up steps on batch 0, then one replay per further batch
+    plain = H.build_distiller(opt, g['student_shapes'])
+    for i, b in enumerate(order):
+        plain.set_input(batches[b])
+        plain.optimize_parameters(i)
+    eager = H.build_distiller(opt, g['student_shapes'])
+    eager.enable_data_parallel(parallel.DataParallelReducer(), overlap=True)
+    for i, b in enumerate(order):
+        eager.set_input(batches[b])
+        eager.optimize_parameters(i)
+    assert eager._pending_G is not None
+    eager.finish_pending()
+    graphed = H.build_distiller(opt, g['student_shapes'])
+    graphed.enable_data_parallel(parallel.DataParallelReducer(), overlap=True)
+    step = GraphedDPStep(graphed, batches[0], warmup=2)
+    for b in order[2:]:
+        step(batches[b])
+    losses_g = {k: float(v) for k, v in graphed.get_current_losses().items()}      # finish_pending not needed for the loss terms
+    graphed.finish_pending()
+    torch.cuda.synchronize()
+
+    def same(a, b):
+        bad = [k for (k, va), (_, vb) in zip(a.state_dict().items(), b.state_dict().items()) if not torch.equal(va, vb)]
+        return bad
+    out = dict(version=version,
+               eager_S=same(eager.netG_student, plain.netG_student), eager_D=same(eager.netD, plain.netD),
+               graph_S=same(graphed.netG_student, plain.netG_student), graph_D=same(graphed.netD, plain.netD),
+               losses_plain={k: float(v) for k, v in plain.get_current_losses().items()},
+               losses_eager={k: float(v) for k, v in eager.get_current_losses().items()}, losses_graph=losses_g,
+               steps=(plain.optimizer_G._flat[0]['step'], eager.optimizer_G._flat[0]['step'], graphed.optimizer_G._flat[0]['step'],
+                      graphed.optimizer_D._flat[0]['step']))
+    q.put((0, out))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_single_rank_rccl_schedule_is_bit_identical_to_plain_step():
+    """RCCL itself in the loop (a world_size-1 'nccl' process group: library load, device_id= initialisation, all-reduce on the real
+    flat gradient buckets, Work.wait() stream ordering): the data-parallel schedule -- launched eagerly and as hipGraph segments around
+    the collectives -- must reproduce the plain single-GPU step bit for bit (same kernels; all-reduce over one rank is the identity,
+    the KA seed factor and the gradient scale are 1)."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_single_rank_rccl, args=(0, 1, _free_port(), q))
+    p.start()
+    _, out = q.get(timeout=600)
+    p.join(600)
+    assert p.exitcode == 0
+    print('\n[dp] collective backend:', out['version'])
+    assert out['version'].startswith('rccl')
+    assert out['steps'] == (5, 5, 5, 5), out['steps']
+    for k in ('eager_S', 'eager_D', 'graph_S', 'graph_D'):
+        assert out[k] == [], (k, out[k][:5])
+    for k, v in out['losses_plain'].items():
+        assert out['losses_eager'][k] == v and out['losses_graph'][k] == v, (k, v, out['losses_eager'][k], out['losses_graph'][k])

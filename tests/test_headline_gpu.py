@@ -45,22 +45,51 @@ def c2_ragged():
     ops.set_tconv_min_tiles(old)
 
 
+@pytest.fixture(scope='module')
+def c3():
+    """BASELINE configs[2] per GPU: InstanceNorm (affine), lsgan, unaligned (recon against the teacher's output, D sees
+    3 channels), ndf 64, student S_2.6 -- at 256 x 256 through the fused InstanceNorm blocks and the LDS-tile kernels."""
+    import bench
+    from cat_amd import _lib, ops
+    _lib.load()
+    old = ops.set_tconv_min_tiles(1)
+    args = argparse.Namespace(workload='c3', batch=2, size=256, target_flops=2.6e9)
+    model, opt = bench.build_model(args, 0)
+    yield model, opt
+    ops.set_tconv_min_tiles(old)
+
+
 def test_c2_step_at_256_matches_oracle(c2, capsys):
-    _step_vs_oracle(c2, capsys, 2, 256)
+    _step_vs_oracle(c2, capsys, 2, 256, fp64=True)
 
 
 def test_c2_step_at_ragged_232_matches_oracle(c2_ragged, capsys):
     _step_vs_oracle(c2_ragged, capsys, 3, 232)
 
 
-def _step_vs_oracle(fix, capsys, nimg, size):
+def test_c3_step_at_256_matches_oracle(c3, capsys):
+    from cat_amd import fused_block, nn as cnn
+    model, opt = c3
+    blk = model.netG_student.features[0]
+    assert isinstance(blk.pw_bn, cnn.InstanceNorm2d) and fused_block._ENABLED
+    _step_vs_oracle(c3, capsys, 2, 256, fp64=True, tag='C3 ')
+
+
+def _step_vs_oracle(fix, capsys, nimg, size, fp64=False, tag=''):
+    """fp64=True: the oracle step is also evaluated in fp64 (same weights / images) and the student's gradients are judged against
+    it, next to the oracle's own fp32-vs-fp64 deviation (test_spade_gpu.check_grads)."""
+    import bench
+    import test_spade_gpu as TS
     from cat_amd import ops
     model, opt = fix
-    ncfg = {'norm': 'batch', 'eps': opt.norm_epsilon, 'momentum': opt.norm_momentum}
-    cfg = dict(T=ncfg, S=ncfg, D=ncfg, dataset_mode='aligned', gan_mode='hinge', lambda_recon=100.0, lambda_distill=1.3, lambda_gan=1.0, lr=opt.lr,
-               beta1=opt.beta1)
+    cfg = bench.oracle_cfg(opt)
     st = ref_cpu.DistillState(_cpu(model.netG_teacher), _cpu(model.netG_student), _cpu(model.netD), cfg)
     A, B = detfill.images((nimg, 3, size, size), 71), detfill.images((nimg, 3, size, size), 72)
+    grads64 = None
+    if fp64:
+        st64 = ref_cpu.DistillState(TS.to64(st.T), TS.to64(st.S), TS.to64(st.D), cfg)
+        ref_cpu.distill_step(st64, A.double(), B.double())
+        grads64 = st64.grads_S
     ref = ref_cpu.distill_step(st, A, B)
     model.set_input({'A': A, 'B': B, 'A_paths': [], 'B_paths': []})
     ops.STATS['conform_copies'] = 0
@@ -75,9 +104,9 @@ def _step_vs_oracle(fix, capsys, nimg, size):
     model.optimizer_G.zero_grad()
     model.backward_G(0)
     torch.cuda.synchronize()
-    import test_spade_gpu as TS
     with capsys.disabled():
-        TS.check_grads(model.netG_student.named_parameters(), st.grads_S)      # prints worst / median / share of tensors within 1e-3
+        print()
+        TS.check_grads(model.netG_student.named_parameters(), st.grads_S, grads64, label='[%sstudent gradients @%dx%d, batch %d]' % (tag, size, size, nimg))
     model.optimizer_G.step()
     torch.cuda.synchronize()
     got = model.get_current_losses()
@@ -102,7 +131,7 @@ def _step_vs_oracle(fix, capsys, nimg, size):
             assert d.max() <= 2.5 * opt.lr + 2e-3 * scale, (name, k, d.max(), scale)
     report['weights_q75'] = worst_q
     with capsys.disabled():
-        print('\n[headline parity @%dx%d, batch %d] max relative deviation from the CPU oracle: ' % (size, size, nimg) + json.dumps({k: float('%.3g' % v) for k, v in report.items()}))
+        print('\n[%sheadline parity @%dx%d, batch %d] max relative deviation from the CPU oracle: ' % (tag, size, size, nimg) + json.dumps({k: float('%.3g' % v) for k, v in report.items()}))
     assert ops.STATS['conform_copies'] == 0
     for k, v in report.items():
         assert v < 1e-3, (k, v)
@@ -189,31 +218,39 @@ def test_evaluate_model_on_gpu(c2, tmp_path):
     assert os.path.exists(os.path.join(str(tmp_path), 'eval', '7', 'Sfake', '1_b.png'))
 
 
-@pytest.mark.timeout(900)
+@pytest.mark.timeout(1500)
 def test_spade_step_at_512x256_matches_oracle(capsys):
     """BASELINE configs[3] at its real size: the bench's own GauGAN model (teacher ngf 64, student ngf 48 pruned to 5.6e9 MACs, multiscale
-    SN-PatchGAN ndf 64, VGG feature loss, KA) -- one SPADEDistiller.optimize_parameters at 512 x 256, batch 1, against
-    oracle/ref_spade_cpu.spade_step on the same weights / labels / image (~30-60 s of host work)."""
+    SN-PatchGAN ndf 64, VGG feature loss, KA) -- one SPADEDistiller.optimize_parameters at 512 x 256 against
+    oracle/ref_spade_cpu.spade_step on the same weights / labels / images.  Batch 2: with one sample KA == 1 identically, so
+    the three distillation terms would compare nothing.  Losses, both fake images, the student's and the discriminator's gradients
+    (against the fp64 evaluation of the same step, next to the oracle's own fp32 deviation) and the updated weights are compared."""
     import bench
+    import test_spade_gpu as TS
     from cat_amd import _lib, ops
     from oracle import ref_spade_cpu as R
     _lib.load()
+    nb = 2
     old = ops.set_tconv_min_tiles(1)
     try:
-        args = argparse.Namespace(workload='spade', batch=1, size=256, target_flops=5.6e9)
+        args = argparse.Namespace(workload='spade', batch=nb, size=256, target_flops=5.6e9)
         model, opt = bench.build_spade_model(args, 0)
         m = model.modules_on_one_gpu
         vsd = {k.split('.', 1)[1]: v for k, v in _cpu(m.criterionVGG.vgg).items()}
         cfg = dict(G=dict(crop_size=opt.crop_size, aspect_ratio=opt.aspect_ratio, num_upsampling_layers=opt.num_upsampling_layers), num_D=2,
                    n_layers_D=4, lambda_gan=1.0, lambda_feat=10.0, lambda_vgg=10.0, lambda_distill=0.5, lr=opt.lr, beta1=0.5, beta2=0.999,
                    no_TTUR=False)
-        st = R.SpadeState(_cpu(m.netG_teacher), _cpu(m.netG_student), _cpu(m.netD), vsd, cfg)
+        sdT, sdS, sdD = _cpu(m.netG_teacher), _cpu(m.netG_student), _cpu(m.netD)
+        st = R.SpadeState(sdT, sdS, sdD, vsd, cfg)
+        st64 = R.SpadeState(TS.to64(sdT), TS.to64(sdS), TS.to64(sdD), TS.to64(vsd), cfg)
         h, w = 256, 512
         rng = np.random.default_rng(5)
-        lab = torch.from_numpy(np.repeat(np.repeat(rng.integers(0, 35, (1, 1, h // 16, w // 16)), 16, 2), 16, 3))
-        ins = torch.from_numpy(np.repeat(np.repeat(rng.integers(0, 1000, (1, 1, h // 16, w // 16)), 16, 2), 16, 3).astype(np.int32))
-        img = detfill.images((1, 3, h, w), 6)
-        R.spade_step(st, R.preprocess_input(lab, ins, 35), img)
+        lab = torch.from_numpy(np.repeat(np.repeat(rng.integers(0, 35, (nb, 1, h // 16, w // 16)), 16, 2), 16, 3))
+        ins = torch.from_numpy(np.repeat(np.repeat(rng.integers(0, 1000, (nb, 1, h // 16, w // 16)), 16, 2), 16, 3).astype(np.int32))
+        img = detfill.images((nb, 3, h, w), 6)
+        sem = R.preprocess_input(lab, ins, 35)
+        R.spade_step(st64, sem.double(), img.double())
+        R.spade_step(st, sem, img)
         ops.STATS['conform_copies'] = 0
         model.set_input({'label': lab.cuda(), 'instance': ins.cuda(), 'image': img.cuda(), 'path': []})
         model.optimize_parameters(0)
@@ -222,10 +259,29 @@ def test_spade_step_at_512x256_matches_oracle(capsys):
         ops.set_tconv_min_tiles(old)
     got = {k.split('/')[-1]: v for k, v in model.get_current_losses().items()}
     report = {k: abs(got[k] - v) / max(abs(v), 1e-2) for k, v in st.losses.items() if k in got}
+    assert all(abs(st.losses['G_distill%d' % i] + 1.0) > 1e-4 for i in range(3)), 'KA terms degenerate (== -1): nothing compared'
     report['Sfake_B'] = H.rel_err(model.Sfake_B.detach().cpu().numpy(), st.Sfake_B.numpy())
     report['Tfake_B'] = H.rel_err(model.Tfake_B.detach().cpu().numpy(), st.Tfake_B.numpy())
     with capsys.disabled():
-        print('\n[headline parity SPADE @512x256, batch 1] max relative deviation from the CPU oracle: ' + json.dumps({k: float('%.3g' % v) for k, v in report.items()}))
+        print('\n[headline parity SPADE @512x256, batch %d] max relative deviation from the CPU oracle: ' % nb +
+              json.dumps({k: float('%.3g' % v) for k, v in report.items()}))
+        # the flat gradient buffers still hold the G step's (student) and the D step's (discriminator) gradients after the step
+        TS.check_grads(m.netG_student.named_parameters(), st.grads_S, st64.grads_S, label='[SPADE student gradients @512x256, batch %d]' % nb)
+        TS.check_grads(m.netD.named_parameters(), st.grads_D, st64.grads_D, label='[SPADE discriminator gradients @512x256, batch %d]' % nb)
     assert ops.STATS['conform_copies'] == 0
     for k, v in report.items():
         assert v < 2e-3, (k, v)
+    # updated weights (TTUR Adam, beta1 = 0: the first step is -lr * sign(grad)): the bulk of every tensor agrees to round-off, nothing moves
+    # further than a flipped first step
+    worst_q = 0.0
+    for name, net, ref_sd, lr in (('S', m.netG_student, st.S, opt.lr / 2), ('D', m.netD, st.D, opt.lr * 2)):
+        for k, v in net.state_dict().items():
+            if not v.dtype.is_floating_point or k.endswith(('weight_u', 'weight_v')) or k.endswith('.weight') and k[:-7] + '.weight_orig' in ref_sd:
+                continue
+            d = (v.detach().cpu() - ref_sd[k]).abs().reshape(-1).numpy()
+            scale = float(ref_sd[k].abs().max()) + 1e-12
+            worst_q = max(worst_q, float(np.quantile(d, 0.75)) / max(scale, 10 * lr))
+            assert d.max() <= 2.5 * lr + 2e-3 * scale, (name, k, float(d.max()), scale)
+    with capsys.disabled():
+        print('[headline parity SPADE] updated weights: worst 75 %% quantile %.3g of max(|w|, 10 lr)' % worst_q)
+    assert worst_q < 1e-3

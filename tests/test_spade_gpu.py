@@ -252,33 +252,60 @@ def make_G(opt, ngf, sd, train):
     return G.train() if train else G.eval()
 
 
-def check_grads(named_params, ref_grads, frac_tight=None):
+def to64(sd):
+    """fp64 copy of a state_dict (integer buffers unchanged): the oracle's functions are dtype-agnostic."""
+    return {k: (v.double() if v.dtype.is_floating_point else v.clone()) for k, v in sd.items()}
+
+
+def check_grads(named_params, ref_grads, ref_grads64=None, label='grad parity'):
     """Parameter-gradient parity for a whole network.
 
     A handful of the ~10^6 ReLU / LeakyReLU / L1 / hinge pre-activations of a layer lie within fp32 round-off of the kink; which
-    side they fall on differs between ANY two evaluation orders (GPU vs CPU oracle, or torch CPU with another thread count), and a
+    side they fall on differs between ANY two fp32 evaluation orders (GPU vs CPU oracle, or torch CPU with another thread count), and a
     flipped unit moves the heavily cancelling sums that form bias / weight gradients by O(1e-3) of the gradient scale -- for
-    every parameter of the branch it sits in (measured: 2 flipped units of 786 432 in up_3's SPADE account for the whole deviation
-    of its gamma/beta convs; the same kernels agree to 1e-6 on inputs without a borderline unit, test_spade_modulation).
-    Hence two criteria:
-      * every tensor: max error <= 5e-3 of the network's largest gradient entry;
-      * the MEDIAN tensor: 1e-3 relative to max(own max, 3 % of the global max)  (tensors whose true gradient is ~0 -- biases in
-        front of a norm -- hold only round-off)."""
+    every parameter of the branch it sits in.  The size of that effect is MEASURED, not assumed: with `ref_grads64` (the same oracle
+    step evaluated in fp64 on the same weights and inputs) every tensor gets two numbers in the same unit, max |d| / max(own max,
+    3 % of the network's largest gradient entry):
+        gpu64 = GPU (fp32 kernels) vs the fp64 gradient          ref64 = the oracle's own fp32 gradient vs the fp64 gradient
+    Two independent fp32 evaluations cannot be compared tensor by tensor (each lands on its own side of its own borderline units), so
+    the bar is on the distributions: median, 90 % quantile and worst tensor of gpu64 must not exceed 2x the oracle's own fp32 figure
+    (+ 1e-3).  tools/oracle_fp64_calibration.py prints the ref64 column alone (CPU only).  Without `ref_grads64` (small fixtures): every
+    tensor within 5e-3 of the network's largest gradient entry and the median tensor within 1e-3 of its own scale."""
     gmax = max(float(v.abs().max()) for v in ref_grads.values())
-    errs = []
+    rows = []
     for k, p in named_params:
         if k not in ref_grads:
             continue
-        own = float(ref_grads[k].abs().max())
-        err = float((p.grad.detach().cpu().double() - ref_grads[k].double()).abs().max())
-        errs.append((err / max(own, 3e-2 * gmax), err / gmax, k))
-    errs.sort(reverse=True)
-    worst_abs = max(e[1] for e in errs)
-    median = errs[len(errs) // 2][0]
-    tight = sum(1 for e in errs if e[0] < 1e-3) / len(errs)
-    print('grad parity: worst err/gmax %.2e, median rel err %.2e, tensors within 1e-3: %.1f %%, worst: %s' % (worst_abs, median, 100 * tight, errs[:3]))
-    assert worst_abs <= 5e-3, errs[:5]
-    assert median <= 1e-3, (median, errs[:8])
+        got = p.grad.detach().cpu().double()
+        r32 = ref_grads[k].double()
+        scale = max(float(r32.abs().max()), 3e-2 * gmax)
+        err = float((got - r32).abs().max())
+        row = dict(k=k, rel=err / scale, abs=err / gmax)
+        if ref_grads64 is not None:
+            r64 = ref_grads64[k].double()
+            row['gpu64'] = float((got - r64).abs().max()) / scale
+            row['ref64'] = float((r32 - r64).abs().max()) / scale
+        rows.append(row)
+    rel = np.array([r['rel'] for r in rows])
+    worst_abs = max(r['abs'] for r in rows)
+    top = sorted(rows, key=lambda r: -r['rel'])[:3]
+    print('%s vs the fp32 oracle: worst err/gmax %.2e, median rel err %.2e, tensors within 1e-3: %.1f %%, worst: %s' %
+          (label, worst_abs, float(np.median(rel)), 100 * float((rel < 1e-3).mean()), [(r['k'], float('%.2e' % r['rel'])) for r in top]))
+    if ref_grads64 is None:
+        assert worst_abs <= 5e-3, top
+        assert float(np.median(rel)) <= 1e-3, (float(np.median(rel)), top)
+        return
+    g64, r64 = np.array([r['gpu64'] for r in rows]), np.array([r['ref64'] for r in rows])
+    stats = {}
+    for name, fn in (('median', np.median), ('q90', lambda a: np.quantile(a, 0.9)), ('worst', np.max)):
+        stats[name] = (float(fn(g64)), float(fn(r64)))
+    print('%s vs the fp64 oracle [GPU | the fp32 oracle itself]: median %.2e | %.2e, 90 %% quantile %.2e | %.2e, worst tensor %.2e | %.2e, '
+          'tensors within 1e-3: %.1f %% | %.1f %%' % (label, *stats['median'], *stats['q90'], *stats['worst'], 100 * float((g64 < 1e-3).mean()),
+                                                       100 * float((r64 < 1e-3).mean())))
+    for r in sorted(rows, key=lambda r: -r['gpu64'])[:3]:
+        print('    %-44s gpu64 %.2e   ref64 %.2e' % (r['k'], r['gpu64'], r['ref64']))
+    for name, (a, b) in stats.items():
+        assert a <= 2.0 * b + 1e-3, (label, name, a, b)
 
 
 @pytest.mark.parametrize('which', ['student_train', 'teacher_eval'])

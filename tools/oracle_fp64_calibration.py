@@ -1,0 +1,72 @@
+"""How far is the CPU oracle's OWN fp32 gradient from the exact (fp64) gradient of the same step?  Calibration for the network-level
+gradient parity bars (tests/test_spade_gpu.py::check_grads): the C2 headline step (256 x 256, batch 2, pruned 4.6e9-MAC student,
+ndf-128 PatchGAN, hinge + 100 L1 + 1.3 KA) is run twice on the host -- fp32 and fp64, same weights and images -- and the per-tensor
+deviation of the student's parameter gradients is printed in the units check_grads uses (max |d| / max(own max, 3 % of the global max)).
+Runs on CPU only (no GPU, no reference import):   python tools/oracle_fp64_calibration.py [size] [batch]"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+
+def c2_state_dicts():
+    import helpers as H
+    from cat_amd import networks, prune, synthetic
+    opt = synthetic.default_options(norm='batch', track=True, ndf=128, dataset_mode='aligned', gan_mode='hinge', lambda_recon=100.0,
+                                    lambda_distill=1.3, target_flops=4.6e9, prune_cin_lb=16, student_ngf=32, gpu_ids=[])
+    torch.manual_seed(233)
+    T = networks.define_G(3, 3, 64, 'inception_9blocks', 'batch', 0, 'normal', 0.02, [], opt=opt)
+    T.load_state_dict(synthetic.fill_state_dict(T.state_dict(), synthetic.SEED_TEACHER, gamma_abs_normal=True))
+    T.eval()
+    import copy
+    thr, _ = prune.search_threshold(T, 4.6e9, opt)
+    S = copy.deepcopy(T)
+    prune._apply_structure(S, T, thr, opt, copy_weights=True)
+    S = networks.init_net(S, 'normal', 0.02, [])
+    D = networks.define_D(6, 128, 'n_layers', 3, 'batch', 'normal', 0.02, [], opt=opt)
+    cpu = lambda net: {k: v.detach().clone() for k, v in net.state_dict().items()}
+    return opt, cpu(T), cpu(S), cpu(D)
+
+
+def to64(sd):
+    return {k: (v.double() if v.dtype.is_floating_point else v.clone()) for k, v in sd.items()}
+
+
+def main():
+    from oracle import detfill, ref_cpu
+    size = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+    nb = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+    opt, T, S, D = c2_state_dicts()
+    ncfg = {'norm': 'batch', 'eps': opt.norm_epsilon, 'momentum': opt.norm_momentum}
+    cfg = dict(T=ncfg, S=ncfg, D=ncfg, dataset_mode='aligned', gan_mode='hinge', lambda_recon=100.0, lambda_distill=1.3, lambda_gan=1.0, lr=opt.lr,
+               beta1=opt.beta1)
+    A, B = detfill.images((nb, 3, size, size), 71), detfill.images((nb, 3, size, size), 72)
+    st32 = ref_cpu.DistillState(T, S, D, cfg)
+    ref_cpu.distill_step(st32, A, B)
+    st64 = ref_cpu.DistillState(to64(T), to64(S), to64(D), cfg)
+    ref_cpu.distill_step(st64, A.double(), B.double())
+    g32, g64 = st32.grads_S, st64.grads_S
+    gmax = max(float(v.abs().max()) for v in g64.values())
+    rows = []
+    for k, v in g64.items():
+        own = float(v.abs().max())
+        err = float((g32[k].double() - v).abs().max())
+        rows.append((err / max(own, 3e-2 * gmax), err / gmax, k))
+    rows.sort(reverse=True)
+    rel = np.array([r[0] for r in rows])
+    print('oracle fp32 vs fp64, student gradients, %d tensors @%dx%d batch %d' % (len(rows), size, size, nb))
+    print('  worst err/gmax %.2e   median rel %.2e   90%% quantile %.2e   tensors within 1e-3: %.1f %%' %
+          (max(r[1] for r in rows), float(np.median(rel)), float(np.quantile(rel, 0.9)), 100 * float((rel < 1e-3).mean())))
+    for r in rows[:8]:
+        print('  %.2e  (%.2e of gmax)  %s' % r)
+    for k in ('G_gan', 'G_recon', 'G_distill'):
+        print('  loss %-10s fp32 %.8f  fp64 %.8f' % (k, st32.losses[k], st64.losses[k]))
+
+
+if __name__ == '__main__':
+    main()
