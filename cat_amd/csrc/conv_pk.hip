@@ -1068,9 +1068,11 @@ int cat_tconv_fwd(const cat_tconv_t* g, const float* pack, const float* bias, fl
     CAT_REQUIRE(sg.cin > 0 && sg.cin <= sg.c4, "tconv: segment %d valid channel count", s);
     kflops += (double)sg.ks * sg.ks * sg.cin;
   }
-  static const int pw_env = getenv("CAT_TCONV_PW") ? atoi(getenv("CAT_TCONV_PW")) : 1;
+  static const int pw_env = getenv("CAT_TCONV_PW") ? atoi(getenv("CAT_TCONV_PW")) : 0;
   static const int pw_nt = getenv("CAT_TCONV_PW_NT") ? atoi(getenv("CAT_TCONV_PW_NT")) : 8;
-  const bool pw = pw_env != 0 && small_src;       // producer-wave kernel (default); CAT_TCONV_PW=0: the register-staged kernel (A/B)
+  // producer-wave kernel: opt-in (CAT_TCONV_PW=1).  Measured on the C2 step (round 3): SLOWER than the register-staged kernel -- teacher
+  // single-segment layers 5.64 -> 6.58 ms, branch sums 6.29 -> 8.13 ms per step -- see DESIGN.md §6; 7 x 7 taps exist only in this variant
+  const bool pw = (pw_env != 0 || hl + hr > 4) && small_src;
   CAT_REQUIRE(hl + hr <= (pw ? 6 : 4), "tconv: halo %d + %d exceeds the staged patch", hl, hr);
   static const int tw_env = getenv("CAT_PK_TW") ? atoi(getenv("CAT_PK_TW")) : 0;
   cat_pk::Launch L;
@@ -1164,7 +1166,7 @@ int cat_tstage1_fwd(const cat_tstage1_t* g, const float* x, const float* const* 
   const size_t lds = (size_t)2 * a.tr * a.tc * cat_pk::PITCH * sizeof(float) + 6 * cat_pk::TABN * sizeof(int) + (size_t)8 * nmax * 16 * sizeof(float);
   hipStream_t s = (hipStream_t)stream;
   cat::ProfScope prof("conv_tstage1", 2.0 * (double)g->N * g->H * g->W * g->cin * kflops, 0.0, stream);
-  static const int pw_env = getenv("CAT_TCONV_PW") ? atoi(getenv("CAT_TCONV_PW")) : 1;
+  static const int pw_env = getenv("CAT_TCONV_PW") ? atoi(getenv("CAT_TCONV_PW")) : 0;
   const bool pw = pw_env != 0 && (int64_t)g->N * g->H * g->W * g->xcs * 4 < (int64_t)2147483647LL;
 #define CAT_S1(NA, NB, NC)                                                                        \
   if (nt[0] == NA && nt[1] == NB && nt[2] == NC) {                                                \

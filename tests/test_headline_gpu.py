@@ -85,6 +85,7 @@ def _step_vs_oracle(fix, capsys, nimg, size, fp64=False, tag=''):
     cfg = bench.oracle_cfg(opt)
     st = ref_cpu.DistillState(_cpu(model.netG_teacher), _cpu(model.netG_student), _cpu(model.netD), cfg)
     A, B = detfill.images((nimg, 3, size, size), 71), detfill.images((nimg, 3, size, size), 72)
+    before = {'S': {k: v.clone() for k, v in st.S.items()}, 'D': {k: v.clone() for k, v in st.D.items()}}
     grads64 = None
     if fp64:
         st64 = ref_cpu.DistillState(TS.to64(st.T), TS.to64(st.S), TS.to64(st.D), cfg)
@@ -125,10 +126,16 @@ def _step_vs_oracle(fix, capsys, nimg, size, fp64=False, tag=''):
                 continue
             d = (v.detach().cpu() - ref_sd[k]).abs().reshape(-1).numpy()
             scale = float(ref_sd[k].abs().max()) + 1e-12
-            q = float(np.quantile(d, 0.75)) / max(scale, 10 * opt.lr)
+            assert d.max() <= 2.5 * opt.lr + 2e-3 * scale, (name, k, d.max(), scale)
+            # elements with a solid gradient move by ~lr in Adam's first step.  A conv bias (or 1x1 depthwise scale) directly in front of
+            # an InstanceNorm has exact gradient 0: both implementations hold round-off there and Adam turns it into anything up to
+            # +-lr -- such elements are bounded by the assert above, the bulk statistic is taken over the solid ones
+            solid = ((ref_sd[k] - before[name][k]).abs() > 0.5 * opt.lr).reshape(-1).numpy()
+            if solid.sum() < 8:
+                continue
+            q = float(np.quantile(d[solid], 0.75)) / max(scale, 10 * opt.lr)
             if q > worst_q:
                 worst_q, worst_k = q, (name, k, float(d.max()), scale)
-            assert d.max() <= 2.5 * opt.lr + 2e-3 * scale, (name, k, d.max(), scale)
     report['weights_q75'] = worst_q
     with capsys.disabled():
         print('\n[%sheadline parity @%dx%d, batch %d] max relative deviation from the CPU oracle: ' % (tag, size, size, nimg) + json.dumps({k: float('%.3g' % v) for k, v in report.items()}))
