@@ -98,6 +98,72 @@ __device__ __forceinline__ void mma_groups(f4 (&acc)[MT][NT], const float* tile,
   }
 }
 
+// mma_groups with the filter stream pipelined ACROSS calls (tstage1_kernel: 5x5 -> 3x3 -> 1x1 -> next chunk's 5x5, each with its own
+// resource / tile count).  A plain call starts with a cold buffer_load -> s_waitcnt -> MFMA sequence: one L2 round trip per
+// sub-convolution, three per 16-channel chunk.  Here `b0` holds this stream's first group on entry (requested by the previous call) and
+// the last group requests the FOLLOWING stream's first group into that stream's own `n0`.  Same MFMA order as mma_groups: results are
+// bit-identical.  (The same chaining inside tconv_kernel -- operand sets persisting over the chunks -- was compiled and dropped: the
+// dynamic set parity doubles the accumulator registers, 220 -> 324 VGPRs at 8 N tiles, one workgroup per CU.)
+template <int MT, int NT, int NTN>
+__device__ __forceinline__ void mma_groups_pf(f4 (&acc)[MT][NT], const float* tile, const int* tab, const int (&abase)[MT],
+                                              const __amdgpu_buffer_rsrc_t rsrc, const unsigned (&jb)[NT], unsigned so, unsigned gbytes, int ngr,
+                                              f4 (&b0)[NT], const __amdgpu_buffer_rsrc_t rsrc_n, const unsigned (&jb_n)[NTN], unsigned so_n,
+                                              f4 (&n0)[NTN], bool has_next) {
+  const int last = ngr - 1;
+  f4 a0[MT], a1[MT], b1[NT];
+  int off = tab[0];
+  int offn = tab[4 * min(1, last)];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) a0[i] = *reinterpret_cast<const f4*>(tile + abase[i] + off);
+  int gi = 0;
+  while (true) {
+    {
+      const int g2 = min(gi + 2, last);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) a1[i] = *reinterpret_cast<const f4*>(tile + abase[i] + offn);
+      if (gi < last) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) b1[j] = bload(rsrc, jb[j], so + (unsigned)(gi + 1) * gbytes);
+      } else if (has_next) {
+#pragma unroll
+        for (int j = 0; j < NTN; ++j) n0[j] = bload(rsrc_n, jb_n[j], so_n);
+      }
+      offn = tab[4 * g2];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int tq = 0; tq < 4; ++tq)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i][tq], b0[j][tq], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (++gi >= ngr) break;
+    {
+      const int g2 = min(gi + 2, last);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) a0[i] = *reinterpret_cast<const f4*>(tile + abase[i] + offn);
+      if (gi < last) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) b0[j] = bload(rsrc, jb[j], so + (unsigned)(gi + 1) * gbytes);
+      } else if (has_next) {
+#pragma unroll
+        for (int j = 0; j < NTN; ++j) n0[j] = bload(rsrc_n, jb_n[j], so_n);
+      }
+      offn = tab[4 * g2];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int tq = 0; tq < 4; ++tq)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[i][tq], b1[j][tq], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (++gi >= ngr) break;
+  }
+}
+
 template <int NT, int TW>
 __global__ __launch_bounds__(256) void tconv_kernel(const cat_tconv_t g, const float* __restrict__ pack, const float* __restrict__ bias,
                                                     float* __restrict__ y, const Launch L) {
@@ -815,6 +881,11 @@ __global__ __launch_bounds__(256) void tstage1_kernel(const S1Args p) {
 #pragma unroll
   for (int j = 0; j < (NC > 0 ? NC : 1); ++j) jbC[j] = (unsigned)(min(j, max(p.nt_total[2], 1) - 1) * 64 + lane) * 16u;
   unsigned soA = 0, soB = 0, soC = 0;     // byte offsets of the current chunk in the three streams
+  static_assert(NA > 0 && NB > 0 && NC > 0, "tstage1: all three kernel sizes (cat_tstage1_supported)");
+  // first filter group of each sub-convolution, requested while the previous one's last group computes (A -> B -> C -> next chunk's A)
+  f4 bA[NA], bB[NB], bC[NC];
+#pragma unroll
+  for (int j = 0; j < NA; ++j) bA[j] = bload(rA, jbA[j], 0u);
   gload(0);
   sstore(0, 0);
   __syncthreads();
@@ -825,20 +896,14 @@ __global__ __launch_bounds__(256) void tstage1_kernel(const S1Args p) {
     const int nq = min(4, (p.c4 - c0) >> 2);
     const float* tile = tile0 + buf * tile_floats;
     const int* tab = tab0 + buf * 3 * TABN + lq;
-    if constexpr (NA > 0) {
-      const int ngr = (25 * nq + 3) >> 2;
-      mma_groups<MT, NA>(accA, tile, tab, abase, rA, jbA, soA, (unsigned)p.nt_total[0] * 1024u, ngr);
-      soA += (unsigned)ngr * p.nt_total[0] * 1024u;
-    }
-    if constexpr (NB > 0) {
-      const int ngr = (9 * nq + 3) >> 2;
-      mma_groups<MT, NB>(accB, tile, tab + TABN, abase, rB, jbB, soB, (unsigned)p.nt_total[1] * 1024u, ngr);
-      soB += (unsigned)ngr * p.nt_total[1] * 1024u;
-    }
-    if constexpr (NC > 0) {
-      mma_groups<MT, NC>(accC, tile, tab + 2 * TABN, abase, rC, jbC, soC, (unsigned)p.nt_total[2] * 1024u, 1);
-      soC += (unsigned)p.nt_total[2] * 1024u;
-    }
+    const int ngrA = (25 * nq + 3) >> 2, ngrB = (9 * nq + 3) >> 2;
+    const unsigned soA_n = soA + (unsigned)ngrA * p.nt_total[0] * 1024u;
+    mma_groups_pf<MT, NA, NB>(accA, tile, tab, abase, rA, jbA, soA, (unsigned)p.nt_total[0] * 1024u, ngrA, bA, rB, jbB, soB, bB, true);
+    mma_groups_pf<MT, NB, NC>(accB, tile, tab + TABN, abase, rB, jbB, soB, (unsigned)p.nt_total[1] * 1024u, ngrB, bB, rC, jbC, soC, bC, true);
+    mma_groups_pf<MT, NC, NA>(accC, tile, tab + 2 * TABN, abase, rC, jbC, soC, (unsigned)p.nt_total[2] * 1024u, 1, bC, rA, jbA, soA_n, bA, more);
+    soA = soA_n;
+    soB += (unsigned)ngrB * p.nt_total[1] * 1024u;
+    soC += (unsigned)p.nt_total[2] * 1024u;
     if (more) {
       sstore(buf ^ 1, c0 + 16);
       __syncthreads();

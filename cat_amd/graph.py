@@ -90,30 +90,35 @@ class GraphedStep:
 
 
 class GraphedDPStep:
-    """The data-parallel InceptionDistiller step (InceptionDistiller._optimize_parameters_dp) as hipGraph SEGMENTS around its two
-    collectives, so that the N-GPU job launches its kernels the way the one-GPU headline run does:
+    """The InceptionDistiller step as hipGraph SEGMENTS: the frozen teacher's forward is its own graph on a side stream, and -- with data
+    parallelism -- the two collectives sit between the segments, so that the N-GPU job launches its kernels the way the one-GPU
+    headline run does (InceptionDistiller._optimize_parameters_dp is the eager form of the same schedule):
 
         main : g_in  (set_input: layout kernels into static buffers)
         side : g_T   (frozen-teacher forward of this batch -- overlaps the wait for the previous step's student all-reduce)
         main : [wait G bucket of the previous step -> Adam G (one eager launch)] -> g_A (student forward, backward_D)
                -> RCCL all-reduce of the D bucket -> join side -> g_B (Adam D, backward_G) -> async all-reduce of the G bucket
 
-    g_T has its own memory pool (it runs concurrently with g_A); g_A / g_B share one (the autograd tape of the student forward is
-    consumed by backward_G) and are always replayed in capture order.  Collectives are never captured: RCCL enqueues them between the
-    graph launches with ordinary stream ordering.  The SPADE step exchanges SynchronizedBatchNorm statistics inside its passes
-    (dozens of small collectives) and stays eager."""
+    Without a reducer (one GPU, `model.dp is None`) the same four graphs run with no collective in between and Adam G at the end of g_B:
+    the teacher then simply overlaps the student forward + discriminator step.  g_T has its own memory pool (it runs concurrently with
+    g_A); g_A / g_B share one (the autograd tape of the student forward is consumed by backward_G) and are always replayed in capture
+    order.  Collectives are never captured: RCCL enqueues them between the graph launches with ordinary stream ordering.  The SPADE step
+    exchanges SynchronizedBatchNorm statistics inside its passes (dozens of small collectives) and stays eager."""
 
     def __init__(self, model, example_batch, warmup=3):
-        if getattr(model, 'dp', None) is None or not hasattr(model, '_dp_first'):
-            raise RuntimeError('GraphedDPStep: needs an InceptionDistiller with enable_data_parallel(...)')
+        if not hasattr(model, '_dp_first'):
+            raise RuntimeError('GraphedDPStep: needs an InceptionDistiller')
         self.model = model
+        self.dp = getattr(model, 'dp', None) is not None
         dev = model.device
+        if getattr(model, '_side_stream', None) is None:
+            model._side_stream = torch.cuda.Stream(device=dev)
         self.static = {k: (v.to(dev).clone() if torch.is_tensor(v) else v) for k, v in example_batch.items()}
         cur = torch.cuda.current_stream()
         warm = torch.cuda.Stream()
         warm.wait_stream(cur)
         with torch.cuda.stream(warm):
-            for i in range(warmup):          # eager DP steps (collectives included: every rank does the same)
+            for i in range(warmup):          # eager steps (with a reducer: the DP schedule, collectives included -- every rank does the same)
                 model.set_input(self.static)
                 model.optimize_parameters(i)
             model.finish_pending()
@@ -130,6 +135,8 @@ class GraphedDPStep:
             model._dp_first()
         with torch.cuda.graph(self.g_B, pool=self.g_A.pool(), **kw):
             model._dp_second(warmup)
+            if not self.dp:
+                model.optimizer_G.step()
         torch.cuda.synchronize()
         self._bound = GraphedStep._graph_bindings(self)
         self._stale = False
@@ -160,13 +167,18 @@ class GraphedDPStep:
         with torch.cuda.stream(side):
             self.g_T.replay()
         t_done = side.record_event()
-        m.finish_pending()                      # wait for the previous step's G bucket, Adam G (eager: one launch)
+        if self.dp:
+            m.finish_pending()                  # wait for the previous step's G bucket, Adam G (eager: one launch)
         self.g_A.replay()
-        m.dp.reduce(m.optimizer_D)
+        if self.dp:
+            m.dp.reduce(m.optimizer_D)
         main.wait_event(t_done)
         self.g_B.replay()
         m.optimizer_D.note_graph_replay()       # Adam D ran inside g_B
-        m._pending_G = m.dp.reduce_async(m.optimizer_G)
+        if self.dp:
+            m._pending_G = m.dp.reduce_async(m.optimizer_G)
+        else:
+            m.optimizer_G.note_graph_replay()   # ... and so did Adam G
         if self._stale:
             self._rebind()
         opt_ = getattr(m, 'opt', None)

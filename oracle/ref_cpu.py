@@ -235,6 +235,7 @@ def distill_step(st, real_A, real_B, n_shards=1):
     loss_D = (loss_D_fake + loss_D_real) * 0.5
     loss_D.backward()
     pD = st.params(st.D)
+    st.grads_D = {k: v.grad.clone() for k, v in pD.items() if v.grad is not None}
     adam_step(pD, {k: v.grad for k, v in pD.items()}, st.adam_D, cfg['lr'], cfg['beta1'])
     for v in pD.values():
         v.requires_grad_(False)

@@ -144,3 +144,37 @@ def test_step_contains_only_library_kernels(fused):
     assert not foreign, foreign
     if fused:
         assert any('tconv_kernel' in k for k in names) and any('tnorm_finalize' in k for k in names), sorted(names)
+
+
+def test_segment_graphs_without_reducer_equal_eager():
+    """GraphedDPStep on ONE GPU without a reducer: set_input | teacher (side stream) | student fwd + D bwd | Adam D + G bwd + Adam G as four
+    hipGraphs must reproduce the eager step bit for bit (same kernels, the teacher merely overlaps the student / discriminator work)."""
+    from cat_amd.graph import GraphedDPStep
+    g = H.load('step_bn.npz')
+    meta = json.loads(str(g['meta']))
+
+    def build():
+        opt = H.make_opt(norm=meta['norm'], track=meta['track'], ndf=meta['ndf'], dataset_mode=meta['dataset_mode'], gan_mode=meta['gan_mode'],
+                         lambda_recon=meta['lambda_recon'], lambda_distill=meta['lambda_distill'], student_ngf=16)
+        return H.build_distiller(opt, g['student_shapes'])
+    n, s = meta['nbatch'], meta['size']
+    batches = [{'A': detfill.images((n, 3, s, s), 510 + i).cuda(), 'B': detfill.images((n, 3, s, s), 610 + i).cuda(), 'A_paths': [], 'B_paths': []}
+               for i in range(3)]
+    eager, graphed = build(), build()
+    for i in range(2):
+        eager.set_input(batches[0])
+        eager.optimize_parameters(i)
+    step = GraphedDPStep(graphed, batches[0], warmup=2)
+    assert not step.dp
+    for i in (1, 2, 1):
+        eager.set_input(batches[i])
+        eager.optimize_parameters(2 + i)
+        step(batches[i])
+        le, lg = eager.get_current_losses(), graphed.get_current_losses()
+        for k in le:
+            assert le[k] == lg[k], (k, le[k], lg[k])
+    torch.cuda.synchronize()
+    for a, b in ((graphed.netG_student, eager.netG_student), (graphed.netD, eager.netD)):
+        for (ka, va), (_, vb) in zip(a.state_dict().items(), b.state_dict().items()):
+            assert torch.equal(va, vb), ka
+    assert graphed.optimizer_G._flat[0]['step'] == eager.optimizer_G._flat[0]['step'] == 5
