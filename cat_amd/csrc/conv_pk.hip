@@ -98,72 +98,6 @@ __device__ __forceinline__ void mma_groups(f4 (&acc)[MT][NT], const float* tile,
   }
 }
 
-// mma_groups with the filter stream pipelined ACROSS calls (tstage1_kernel: 5x5 -> 3x3 -> 1x1 -> next chunk's 5x5, each with its own
-// resource / tile count).  A plain call starts with a cold buffer_load -> s_waitcnt -> MFMA sequence: one L2 round trip per
-// sub-convolution, three per 16-channel chunk.  Here `b0` holds this stream's first group on entry (requested by the previous call) and
-// the last group requests the FOLLOWING stream's first group into that stream's own `n0`.  Same MFMA order as mma_groups: results are
-// bit-identical.  (The same chaining inside tconv_kernel -- operand sets persisting over the chunks -- was compiled and dropped: the
-// dynamic set parity doubles the accumulator registers, 220 -> 324 VGPRs at 8 N tiles, one workgroup per CU.)
-template <int MT, int NT, int NTN>
-__device__ __forceinline__ void mma_groups_pf(f4 (&acc)[MT][NT], const float* tile, const int* tab, const int (&abase)[MT],
-                                              const __amdgpu_buffer_rsrc_t rsrc, const unsigned (&jb)[NT], unsigned so, unsigned gbytes, int ngr,
-                                              f4 (&b0)[NT], const __amdgpu_buffer_rsrc_t rsrc_n, const unsigned (&jb_n)[NTN], unsigned so_n,
-                                              f4 (&n0)[NTN], bool has_next) {
-  const int last = ngr - 1;
-  f4 a0[MT], a1[MT], b1[NT];
-  int off = tab[0];
-  int offn = tab[4 * min(1, last)];
-#pragma unroll
-  for (int i = 0; i < MT; ++i) a0[i] = *reinterpret_cast<const f4*>(tile + abase[i] + off);
-  int gi = 0;
-  while (true) {
-    {
-      const int g2 = min(gi + 2, last);
-#pragma unroll
-      for (int i = 0; i < MT; ++i) a1[i] = *reinterpret_cast<const f4*>(tile + abase[i] + offn);
-      if (gi < last) {
-#pragma unroll
-        for (int j = 0; j < NT; ++j) b1[j] = bload(rsrc, jb[j], so + (unsigned)(gi + 1) * gbytes);
-      } else if (has_next) {
-#pragma unroll
-        for (int j = 0; j < NTN; ++j) n0[j] = bload(rsrc_n, jb_n[j], so_n);
-      }
-      offn = tab[4 * g2];
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int tq = 0; tq < 4; ++tq)
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-          for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i][tq], b0[j][tq], acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (++gi >= ngr) break;
-    {
-      const int g2 = min(gi + 2, last);
-#pragma unroll
-      for (int i = 0; i < MT; ++i) a0[i] = *reinterpret_cast<const f4*>(tile + abase[i] + offn);
-      if (gi < last) {
-#pragma unroll
-        for (int j = 0; j < NT; ++j) b0[j] = bload(rsrc, jb[j], so + (unsigned)(gi + 1) * gbytes);
-      } else if (has_next) {
-#pragma unroll
-        for (int j = 0; j < NTN; ++j) n0[j] = bload(rsrc_n, jb_n[j], so_n);
-      }
-      offn = tab[4 * g2];
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int tq = 0; tq < 4; ++tq)
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-          for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[i][tq], b1[j][tq], acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (++gi >= ngr) break;
-  }
-}
-
 template <int NT, int TW>
 __global__ __launch_bounds__(256) void tconv_kernel(const cat_tconv_t g, const float* __restrict__ pack, const float* __restrict__ bias,
                                                     float* __restrict__ y, const Launch L) {
@@ -419,294 +353,6 @@ __global__ __launch_bounds__(256) void tconv_kernel(const cat_tconv_t g, const f
   }
 }
 
-// ------------------------------------------------------------------------------------------------ producer-wave variant
-// What bounded tconv_kernel (ISA: the s_waitcnt vmcnt in front of the first MFMA of a group): the staging global_loads of the NEXT chunk
-// are issued before the chunk's MFMA stream, the filter fragments are buffer_loads issued inside it, and vector-memory loads return IN
-// ORDER -- so the first wait for a filter fragment also waits for the staging loads, one full HBM / L2 latency per 16-channel chunk in
-// every compute wave (pipe busy 0.73-0.82 on the teacher's 16-chunk layers, ~0.6 on the student's one- and two-chunk segments).
-// Here the workgroup has a FIFTH wave that does nothing but stage: it owns the whole patch (PIT float4 slots per lane), keeps the
-// loads of chunk i+2 in flight while it transforms (per-channel affine + activation) and stores chunk i+1, and meets the compute waves
-// at the one barrier per chunk.  The compute waves' vmcnt then only ever counts their own filter-fragment loads.
-template <int MT, int NT, int TW>
-__device__ __forceinline__ void tconv_epilogue(f4 (&acc)[MT][NT], const cat_tconv_t& g, const Launch& L, const float* __restrict__ bias,
-                                               float* __restrict__ y, float* red, int wave, int lr, int lq, int n, int tt, int oy0, int ox0, int j0) {
-  if (g.stats) {
-    // per-tile sum and sum of squared deviations from the TILE mean of the pre-activation output (see tconv_kernel)
-    const int cnt = min(TH, g.Ho - oy0) * min(TW, g.Wo - ox0);
-    float s[NT], mean[NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int co = (j0 + j) * 16 + lr;
-      const float b = (bias && co < g.Nn) ? bias[co] : 0.f;
-      float a = 0.f;
-#pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        const bool rowv = oy0 + 2 * wave + (MT == 2 ? i : (i >> 1)) < g.Ho;
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-          const bool v = rowv && ox0 + (MT == 2 ? 0 : (i & 1) * 16) + lq * 4 + rg < g.Wo;
-          a += v ? acc[i][j][rg] + b : 0.f;
-        }
-      }
-      a += __shfl_xor(a, 16, 64);
-      a += __shfl_xor(a, 32, 64);
-      s[j] = a;
-      if (lq == 0) red[wave * NT * 16 + j * 16 + lr] = a;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int c = j * 16 + lr;
-      s[j] = (red[c] + red[NT * 16 + c]) + (red[2 * NT * 16 + c] + red[3 * NT * 16 + c]);
-      mean[j] = s[j] / (float)cnt;
-    }
-    float* red2 = red + 4 * NT * 16;
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int co = (j0 + j) * 16 + lr;
-      const float b = (bias && co < g.Nn) ? bias[co] : 0.f;
-      float a = 0.f;
-#pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        const bool rowv = oy0 + 2 * wave + (MT == 2 ? i : (i >> 1)) < g.Ho;
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-          const bool v = rowv && ox0 + (MT == 2 ? 0 : (i & 1) * 16) + lq * 4 + rg < g.Wo;
-          const float d = acc[i][j][rg] + b - mean[j];
-          a += v ? d * d : 0.f;
-        }
-      }
-      a += __shfl_xor(a, 16, 64);
-      a += __shfl_xor(a, 32, 64);
-      if (lq == 0) red2[wave * NT * 16 + j * 16 + lr] = a;
-    }
-    __syncthreads();
-    if (wave == 0 && lq == 0) {
-      float* dst = g.stats + (int64_t)tt * 2 * g.scs;
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const int c = j * 16 + lr, co = (j0 + j) * 16 + lr;
-        if (j0 + j < L.nt_total && co < g.ycw) {
-          const bool cv = co < g.Nn;
-          dst[co] = cv ? s[j] : 0.f;
-          dst[g.scs + co] = cv ? (red2[c] + red2[NT * 16 + c]) + (red2[2 * NT * 16 + c] + red2[3 * NT * 16 + c]) : 0.f;
-        }
-      }
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    const int oy = oy0 + 2 * wave + (MT == 2 ? i : (i >> 1));
-    if (oy >= g.Ho) continue;
-#pragma unroll
-    for (int rg = 0; rg < 4; ++rg) {
-      const int ox = ox0 + (MT == 2 ? 0 : (i & 1) * 16) + lq * 4 + rg;
-      if (ox >= g.Wo) continue;
-      float* yo = y + (((int64_t)n * g.Ho + oy) * g.Wo + ox) * g.ycs;
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const int co = (j0 + j) * 16 + lr;
-        if (j0 + j >= L.nt_total) continue;
-        if (co < g.Nn) {
-          float v = cat::apply_act(acc[i][j][rg] + (bias ? bias[co] : 0.f), g.act, g.slope);
-          if (g.res) v += g.res[(((int64_t)n * g.Ho + oy) * g.Wo + ox) * g.rcs + co];
-          yo[co] = v;
-        } else if (co < g.ycw) {
-          yo[co] = 0.f;
-        }
-      }
-    }
-  }
-}
-
-// one chunk on its way global -> registers -> LDS (producer wave only)
-template <int PIT>
-struct Stage {
-  f4 v[PIT];
-  f4 sc, sh;
-  unsigned mask;             // bit it: slot (lane + 64 it) lies inside the source plane (after reflection)
-  int s, c0;                 // segment, first channel of the chunk
-  bool qv;                   // this lane's channel quad exists in the chunk
-};
-
-constexpr unsigned OOB = 0x80000000u;      // voffset beyond num_records: the buffer unit returns zeros (padding / out-of-plane slots)
-
-// QPP = channel quads staged per patch pixel: 4 (a 16-channel chunk), or 1 for sources of <= 4 channels (the 7 x 7 image stem: the
-// 14 x 22 patch is 5 slots per lane instead of 20)
-template <int NT, int TW, int HALO, int QPP>
-__global__ __launch_bounds__(320) void tconv_pw_kernel(const cat_tconv_t g, const float* __restrict__ pack, const float* __restrict__ bias,
-                                                       float* __restrict__ y, const Launch L) {
-  constexpr int MT = TW / 8;
-  constexpr int PIT = ((TH + HALO) * (TW + HALO) * QPP + 63) / 64;
-  constexpr int TN = HALO > 4 ? 256 : TABN;      // A-offset table entries per buffer (7 x 7 taps x 4 quads = 196 pairs)
-  static_assert(PIT <= 32, "slot mask");
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tile_floats = L.tr * L.tc * PITCH;
-  float* tile0 = smem;
-  int* tab0 = reinterpret_cast<int*>(smem + 2 * tile_floats);
-  float* red = smem + 2 * tile_floats + 2 * TN;
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool producer = wave == 4;
-  const int lr = lane & 15, lq = lane >> 4;
-  const int bid = cat::xcd_remap(blockIdx.x, gridDim.x);
-  const int nb = bid % L.nblk, tt = bid / L.nblk;
-  const int n = tt / L.tiles, t = tt - n * L.tiles;
-  const int oy0 = (t / L.tiles_x) * TH, ox0 = (t % L.tiles_x) * TW;
-  const int j0 = nb * NT;
-  const int gstride = L.nt_total * 256;
-
-  int nchunks = 0;
-  for (int s = 0; s < g.nseg; ++s) nchunks += (g.seg[s].c4 + 15) >> 4;
-  struct Cur { int s, c0; int64_t pk; };
-  auto ngr_of = [&](const Cur& c) {
-    const int ks = g.seg[c.s].ks;
-    const int nq = min(4, (g.seg[c.s].c4 - c.c0) >> 2);
-    return (ks * ks * nq + 3) >> 2;
-  };
-  auto advance = [&](Cur& c) {
-    c.pk += (int64_t)ngr_of(c) * gstride;
-    c.c0 += 16;
-    if (c.c0 >= g.seg[c.s].c4) {
-      ++c.s;
-      c.c0 = 0;
-      if (c.s < g.nseg) c.pk = g.seg[c.s].pack_off;
-    }
-  };
-
-  if (producer) {
-    // ---------------------------------------------------------------- staging: this wave owns all slots of the patch
-    constexpr int PSTEP = 64 / QPP;       // patch pixels between consecutive slots of a lane
-    const int slots = L.tr * L.tc * QPP, quad = QPP == 4 ? (lane & 3) : 0;
-    // slot idx = lane + 64 it  ->  patch pixel (idx / QPP), channel quad (idx % QPP); (row, col) of consecutive `it` advance by PSTEP
-    // pixels, so no per-slot state is kept between the chunks -- only the validity bits
-    const int pix0 = QPP == 4 ? (lane >> 2) : lane;
-    const int pr0 = pix0 / L.tc, pc0 = pix0 - pr0 * L.tc;
-    auto load = [&](Stage<PIT>& R, const Cur& c) {
-      const int refl = g.seg[c.s].reflect, xcs = g.seg[c.s].xcs;
-      const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.seg[c.s].src), 0, 0x7fffffff, 0x00020000);
-      R.s = c.s;
-      R.c0 = c.c0;
-      R.qv = c.c0 + quad * 4 < g.seg[c.s].c4;
-      R.mask = 0u;
-      int pr = pr0, pc = pc0;
-      asm volatile("" : "+v"(pr), "+v"(pc));      // opaque per chunk: keeps the compiler from hoisting PIT slots' worth of coordinates / offsets
-                                                  // out of the chunk loop (they would live in ~60 VGPRs across it)
-#pragma unroll
-      for (int it = 0; it < PIT; ++it) {
-        int iy = oy0 - L.hl + pr, ix = ox0 - L.hl + pc;
-        bool v = lane + it * 64 < slots;
-        if (refl) {
-          v = v && iy > -g.H && iy < 2 * g.H - 1 && ix > -g.W && ix < 2 * g.W - 1;
-          iy = cat::reflect_idx(iy, g.H);
-          ix = cat::reflect_idx(ix, g.W);
-        } else {
-          v = v && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
-        }
-        const unsigned off = (((unsigned)(n * g.H + iy) * (unsigned)g.W + (unsigned)ix) * (unsigned)xcs + quad * 4) * 4u;   // < 2^31 bytes (host-checked)
-        R.v[it] = bload(srsrc, (v && R.qv) ? off : OOB, (unsigned)c.c0 * 4u);     // chunk offset in the SGPR soffset
-        R.mask |= v ? (1u << it) : 0u;
-        pc += PSTEP;
-#pragma unroll
-        for (int w = 0; w < (PSTEP + 15) / 16; ++w)       // L.tc >= 16: at most PSTEP / 16 row wraps per step
-          if (pc >= L.tc) {
-            pc -= L.tc;
-            ++pr;
-          }
-        __builtin_amdgcn_sched_barrier(0);      // slot by slot: offset -> load; hoisting all PIT offsets first only costs registers
-      }
-      if (g.seg[c.s].scale != nullptr) {
-        const int so = n * g.seg[c.s].sstride + c.c0 + quad * 4;
-        R.sc = *reinterpret_cast<const f4*>(R.qv ? g.seg[c.s].scale + so : g_zero);
-        R.sh = *reinterpret_cast<const f4*>(R.qv ? g.seg[c.s].shift + so : g_zero);
-      }
-    };
-    auto store = [&](const Stage<PIT>& R, int buf) {
-      float* tile = tile0 + buf * tile_floats;
-      const bool aff = g.seg[R.s].scale != nullptr;
-      const int act = g.seg[R.s].act;
-      const float neg = act == CAT_ACT_RELU ? 0.f : (act == CAT_ACT_LRELU ? g.seg[R.s].slope : 1.f);
-      int l0 = lane;
-      asm volatile("" : "+v"(l0));                // opaque per chunk (same reason: no hoisted per-slot LDS addresses)
-#pragma unroll
-      for (int it = 0; it < PIT; ++it) {
-        const int idx = l0 + it * 64;
-        f4 v = R.v[it];
-        if (aff || act) {   // wave-uniform
-          const bool ok = ((R.mask >> it) & 1u) && R.qv;   // padding pixels / channels stay exactly 0
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float a = aff ? fmaf(v[e], R.sc[e], R.sh[e]) : v[e];
-            a = a > 0.f ? a : a * neg;
-            v[e] = ok ? a : 0.f;
-          }
-        }
-        if (idx < slots) *reinterpret_cast<f4*>(tile + (QPP == 4 ? (idx >> 2) : idx) * PITCH + quad * 4) = v;
-        __builtin_amdgcn_sched_barrier(0);      // transform -> ds_write slot by slot (register pressure of the producer path)
-      }
-      // per-lane-quarter A offsets of every MFMA group of this chunk: pair p = 4 g + lq -> (tap, channel quad)
-      const int ks = g.seg[R.s].ks, taps = ks * ks;
-      const int nq = min(4, (g.seg[R.s].c4 - R.c0) >> 2);
-      const int ngr = (taps * nq + 3) >> 2;
-#pragma unroll
-      for (int e = lane; e < TN; e += 64) {
-        int off = 0;
-        if (e < ngr * 4) {
-          const int tap = e / nq, qd = e - tap * nq;
-          if (tap < taps) {
-            const int ky = tap / ks, kx = tap - ky * ks;
-            const int d = L.hl - g.seg[R.s].padv;
-            off = ((d + ky) * L.tc + d + kx) * PITCH + qd * 4;
-          }
-        }
-        tab0[buf * TN + e] = off;
-      }
-    };
-    // ONE register set is enough: chunk j is stored first, then the loads of chunk j+1 are issued into the same registers and stay in
-    // flight over the barrier and the whole MFMA stream of chunk j-1 ... j.  Barrier k (k = 0 .. nchunks) of this wave pairs with the
-    // compute waves' barrier k: chunk j sits in buffer j & 1 before barrier j, and is overwritten (by chunk j+2) only after barrier j+1,
-    // which the compute waves reach when the MFMA stream of chunk j is done.
-    Cur cp{0, 0, 0};
-    Stage<PIT> R;
-    load(R, cp);
-    for (int j = 0; j < nchunks; ++j) {
-      store(R, j & 1);
-      if (j + 1 < nchunks) {
-        advance(cp);
-        load(R, cp);
-      }
-      __syncthreads();
-    }
-    __syncthreads();
-    return;      // s_barrier only counts the surviving waves: the epilogue's barriers are among the four compute waves
-  }
-
-  // -------------------------------------------------------------------- compute waves: MFMA streams only
-  f4 acc[MT][NT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
-  int abase[MT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    const int row = 2 * wave + (MT == 2 ? i : (i >> 1)), col = (MT == 2 ? 0 : (i & 1) * 16) + lr;
-    abase[i] = (row * L.tc + col) * PITCH;
-  }
-  const __amdgpu_buffer_rsrc_t prsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pack), 0, 0x7fffffff, 0x00020000);
-  unsigned jb[NT];
-#pragma unroll
-  for (int j = 0; j < NT; ++j) jb[j] = (unsigned)(min(j0 + j, L.nt_total - 1) * 64 + lane) * 16u;
-  Cur cc{0, 0, g.seg[0].pack_off};
-  __syncthreads();
-  for (int i = 0; i < nchunks; ++i) {
-    mma_groups<MT, NT>(acc, tile0 + (i & 1) * tile_floats, tab0 + (i & 1) * TN + lq, abase, prsrc, jb, (unsigned)cc.pk * 4u, (unsigned)gstride * 4u,
-                       ngr_of(cc));
-    advance(cc);
-    __syncthreads();
-  }
-  tconv_epilogue<MT, NT, TW>(acc, g, L, bias, y, red, wave, lr, lq, n, tt, oy0, ox0, j0);
-}
-
 // ------------------------------------------------------------------------------------------------ fused first convs of a block
 // All first convs of an InvertedResidualChannels block (inception_modules.py:135-147,150-165: the 5x5, the 3x3 and the N-concatenated
 // 1x1 convs of every branch) from ONE staging of the input tile per 16-channel chunk: three accumulator sets (NA / NB / NC 16-wide
@@ -881,11 +527,6 @@ __global__ __launch_bounds__(256) void tstage1_kernel(const S1Args p) {
 #pragma unroll
   for (int j = 0; j < (NC > 0 ? NC : 1); ++j) jbC[j] = (unsigned)(min(j, max(p.nt_total[2], 1) - 1) * 64 + lane) * 16u;
   unsigned soA = 0, soB = 0, soC = 0;     // byte offsets of the current chunk in the three streams
-  static_assert(NA > 0 && NB > 0 && NC > 0, "tstage1: all three kernel sizes (cat_tstage1_supported)");
-  // first filter group of each sub-convolution, requested while the previous one's last group computes (A -> B -> C -> next chunk's A)
-  f4 bA[NA], bB[NB], bC[NC];
-#pragma unroll
-  for (int j = 0; j < NA; ++j) bA[j] = bload(rA, jbA[j], 0u);
   gload(0);
   sstore(0, 0);
   __syncthreads();
@@ -896,137 +537,6 @@ __global__ __launch_bounds__(256) void tstage1_kernel(const S1Args p) {
     const int nq = min(4, (p.c4 - c0) >> 2);
     const float* tile = tile0 + buf * tile_floats;
     const int* tab = tab0 + buf * 3 * TABN + lq;
-    const int ngrA = (25 * nq + 3) >> 2, ngrB = (9 * nq + 3) >> 2;
-    const unsigned soA_n = soA + (unsigned)ngrA * p.nt_total[0] * 1024u;
-    mma_groups_pf<MT, NA, NB>(accA, tile, tab, abase, rA, jbA, soA, (unsigned)p.nt_total[0] * 1024u, ngrA, bA, rB, jbB, soB, bB, true);
-    mma_groups_pf<MT, NB, NC>(accB, tile, tab + TABN, abase, rB, jbB, soB, (unsigned)p.nt_total[1] * 1024u, ngrB, bB, rC, jbC, soC, bC, true);
-    mma_groups_pf<MT, NC, NA>(accC, tile, tab + 2 * TABN, abase, rC, jbC, soC, (unsigned)p.nt_total[2] * 1024u, 1, bC, rA, jbA, soA_n, bA, more);
-    soA = soA_n;
-    soB += (unsigned)ngrB * p.nt_total[1] * 1024u;
-    soC += (unsigned)p.nt_total[2] * 1024u;
-    if (more) {
-      sstore(buf ^ 1, c0 + 16);
-      __syncthreads();
-      buf ^= 1;
-    }
-  }
-  __syncthreads();
-  if constexpr (NA > 0) s1_epilogue<NA>(accA, p, 0, n, tt, oy0, ox0, wave, lr, lq, red);
-  if constexpr (NB > 0) s1_epilogue<NB>(accB, p, 1, n, tt, oy0, ox0, wave, lr, lq, red);
-  if constexpr (NC > 0) s1_epilogue<NC>(accC, p, 2, n, tt, oy0, ox0, wave, lr, lq, red);
-}
-
-// Producer-wave variant of tstage1_kernel (see tconv_pw_kernel): wave 4 stages the 12 x 20 patch of the next 16-channel chunk while the
-// four compute waves run the three MFMA streams of the current one.
-template <int NA, int NB, int NC>
-__global__ __launch_bounds__(320) void tstage1_pw_kernel(const S1Args p) {
-  constexpr int MT = 2, TW = 16, PIT = ((TH + 4) * (TW + 4) * 4 + 63) / 64;
-  constexpr int NMAX = NA > NB ? (NA > NC ? NA : NC) : (NB > NC ? NB : NC);
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tile_floats = p.tr * p.tc * PITCH;
-  float* tile0 = smem;
-  int* tab0 = reinterpret_cast<int*>(smem + 2 * tile_floats);      // [buf][3][TABN]
-  float* red = smem + 2 * tile_floats + 6 * TABN;                  // [2][4][NMAX * 16]
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int lr = lane & 15, lq = lane >> 4;
-  const int tt = cat::xcd_remap(blockIdx.x, gridDim.x);
-  const int n = tt / p.tiles, t = tt - n * p.tiles;
-  const int oy0 = (t / p.tiles_x) * TH, ox0 = (t % p.tiles_x) * TW;
-  const int nchunks = (p.c4 + 15) >> 4;
-  if (wave == 4) {
-    const int slots = p.tr * p.tc * 4, quad = lane & 3;
-    const int pr0 = (lane >> 2) / p.tc, pc0 = (lane >> 2) - pr0 * p.tc;
-    const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, 0x7fffffff, 0x00020000);
-    f4 v[PIT];
-    auto load = [&](int c0) {
-      const bool qv = c0 + quad * 4 < p.c4;
-      int pr = pr0, pc = pc0;
-      asm volatile("" : "+v"(pr), "+v"(pc));      // opaque per chunk (no hoisted per-slot state, see tconv_pw_kernel)
-#pragma unroll
-      for (int it = 0; it < PIT; ++it) {
-        int iy = oy0 - p.hl + pr, ix = ox0 - p.hl + pc;
-        bool ok = lane + it * 64 < slots;
-        if (p.reflect) {
-          ok = ok && iy > -p.H && iy < 2 * p.H - 1 && ix > -p.W && ix < 2 * p.W - 1;
-          iy = cat::reflect_idx(iy, p.H);
-          ix = cat::reflect_idx(ix, p.W);
-        } else {
-          ok = ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-        }
-        const unsigned off = (((unsigned)(n * p.H + iy) * (unsigned)p.W + (unsigned)ix) * (unsigned)p.xcs + quad * 4) * 4u;
-        v[it] = bload(srsrc, (ok && qv) ? off : OOB, (unsigned)c0 * 4u);
-        pc += 16;
-        if (pc >= p.tc) {
-          pc -= p.tc;
-          ++pr;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    };
-    auto store = [&](int buf, int c0) {
-      float* tile = tile0 + buf * tile_floats;
-      int l0 = lane;
-      asm volatile("" : "+v"(l0));
-#pragma unroll
-      for (int it = 0; it < PIT; ++it) {
-        const int idx = l0 + it * 64;
-        if (idx < slots) *reinterpret_cast<f4*>(tile + (idx >> 2) * PITCH + quad * 4) = v[it];
-      }
-      const int nq = min(4, (p.c4 - c0) >> 2);
-#pragma unroll
-      for (int e = lane; e < TABN; e += 64) {
-        const int tap = e / nq, qd = e - tap * nq;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          const int ks = k == 0 ? 5 : (k == 1 ? 3 : 1), taps = ks * ks;
-          int off = 0;
-          if (e < ((taps * nq + 3) >> 2) * 4 && tap < taps) {
-            const int ky = tap / ks, kx = tap - ky * ks, d = p.hl - (ks >> 1);
-            off = ((d + ky) * p.tc + d + kx) * PITCH + qd * 4;
-          }
-          tab0[(buf * 3 + k) * TABN + e] = off;
-        }
-      }
-    };
-    load(0);
-    for (int j = 0; j < nchunks; ++j) {
-      store(j & 1, j * 16);
-      if (j + 1 < nchunks) load((j + 1) * 16);
-      __syncthreads();
-    }
-    __syncthreads();
-    return;
-  }
-  f4 accA[MT][NA > 0 ? NA : 1], accB[MT][NB > 0 ? NB : 1], accC[MT][NC > 0 ? NC : 1];
-#pragma unroll
-  for (int i = 0; i < MT; ++i) {
-#pragma unroll
-    for (int j = 0; j < (NA > 0 ? NA : 1); ++j) accA[i][j] = f4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int j = 0; j < (NB > 0 ? NB : 1); ++j) accB[i][j] = f4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int j = 0; j < (NC > 0 ? NC : 1); ++j) accC[i][j] = f4{0.f, 0.f, 0.f, 0.f};
-  }
-  int abase[MT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i) abase[i] = ((2 * wave + i) * p.tc + lr) * PITCH;
-  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.pack[0]), 0, 0x7fffffff, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.pack[1]), 0, 0x7fffffff, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.pack[2]), 0, 0x7fffffff, 0x00020000);
-  unsigned jbA[NA > 0 ? NA : 1], jbB[NB > 0 ? NB : 1], jbC[NC > 0 ? NC : 1];
-#pragma unroll
-  for (int j = 0; j < (NA > 0 ? NA : 1); ++j) jbA[j] = (unsigned)(min(j, max(p.nt_total[0], 1) - 1) * 64 + lane) * 16u;
-#pragma unroll
-  for (int j = 0; j < (NB > 0 ? NB : 1); ++j) jbB[j] = (unsigned)(min(j, max(p.nt_total[1], 1) - 1) * 64 + lane) * 16u;
-#pragma unroll
-  for (int j = 0; j < (NC > 0 ? NC : 1); ++j) jbC[j] = (unsigned)(min(j, max(p.nt_total[2], 1) - 1) * 64 + lane) * 16u;
-  unsigned soA = 0, soB = 0, soC = 0;
-  __syncthreads();
-  for (int i = 0; i < nchunks; ++i) {
-    const int c0 = i * 16;
-    const int nq = min(4, (p.c4 - c0) >> 2);
-    const float* tile = tile0 + (i & 1) * tile_floats;
-    const int* tab = tab0 + (i & 1) * 3 * TABN + lq;
     if constexpr (NA > 0) {
       const int ngr = (25 * nq + 3) >> 2;
       mma_groups<MT, NA>(accA, tile, tab, abase, rA, jbA, soA, (unsigned)p.nt_total[0] * 1024u, ngr);
@@ -1041,8 +551,13 @@ __global__ __launch_bounds__(320) void tstage1_pw_kernel(const S1Args p) {
       mma_groups<MT, NC>(accC, tile, tab + 2 * TABN, abase, rC, jbC, soC, (unsigned)p.nt_total[2] * 1024u, 1);
       soC += (unsigned)p.nt_total[2] * 1024u;
     }
-    __syncthreads();
+    if (more) {
+      sstore(buf ^ 1, c0 + 16);
+      __syncthreads();
+      buf ^= 1;
+    }
   }
+  __syncthreads();
   if constexpr (NA > 0) s1_epilogue<NA>(accA, p, 0, n, tt, oy0, ox0, wave, lr, lq, red);
   if constexpr (NB > 0) s1_epilogue<NB>(accB, p, 1, n, tt, oy0, ox0, wave, lr, lq, red);
   if constexpr (NC > 0) s1_epilogue<NC>(accC, p, 2, n, tt, oy0, ox0, wave, lr, lq, red);
@@ -1100,7 +615,7 @@ size_t cat_tconv_pack_floats(int ks, int c4, int Nn) {
 }
 
 int cat_tconv_pack(const float* w, int mode, int Nn, int Ck, int ks, int wcs, int wn, int c4, float* dst, cat_stream_t stream) {
-  CAT_REQUIRE(ks == 1 || ks == 3 || ks == 5 || ks == 7, "tconv pack: kernel size %d unsupported", ks);
+  CAT_REQUIRE(ks == 1 || ks == 3 || ks == 5, "tconv pack: kernel size %d unsupported", ks);
   CAT_REQUIRE(c4 > 0 && (c4 & 3) == 0 && Ck <= c4 && Nn > 0, "tconv pack: bad channel counts (c4=%d Ck=%d Nn=%d)", c4, Ck, Nn);
   CAT_REQUIRE(mode == 0 ? Ck <= wcs : Nn <= wcs, "tconv pack: filter rows shorter than the channels read");
   const int nt = cat::cdiv(Nn, 16);
@@ -1116,15 +631,11 @@ int cat_tconv_fwd(const cat_tconv_t* g, const float* pack, const float* bias, fl
   CAT_REQUIRE(g->res == nullptr || g->rcs >= g->Nn, "tconv: residual stride");
   int hl = 0, hr = 0;
   double kflops = 0.0;
-  bool small_src = true;      // every source below 2 GB: the producer wave addresses them with 32-bit byte offsets
-  bool narrow_src = true;     // every source <= 4 channels
   for (int s = 0; s < g->nseg; ++s) {
     const cat_tseg_t& sg = g->seg[s];
-    small_src = small_src && (int64_t)g->N * g->H * g->W * sg.xcs * 4 < (int64_t)2147483647LL;
-    narrow_src = narrow_src && sg.c4 == 4;
-    CAT_REQUIRE(sg.ks == 1 || sg.ks == 3 || sg.ks == 5 || sg.ks == 7, "tconv: kernel size %d unsupported", sg.ks);
+    CAT_REQUIRE(sg.ks == 1 || sg.ks == 3 || sg.ks == 5, "tconv: kernel size %d unsupported", sg.ks);
     CAT_REQUIRE(sg.c4 > 0 && (sg.c4 & 3) == 0 && (sg.xcs & 3) == 0 && sg.xcs >= sg.c4, "tconv: segment %d channel layout", s);
-    CAT_REQUIRE(sg.padv >= 0 && sg.padv <= 6, "tconv: segment %d padv", s);
+    CAT_REQUIRE(sg.padv >= 0 && sg.padv <= 4, "tconv: segment %d padv", s);
     CAT_REQUIRE(sg.act == CAT_ACT_NONE || sg.act == CAT_ACT_RELU || sg.act == CAT_ACT_LRELU, "tconv: staging activation %d", sg.act);
     CAT_REQUIRE(!sg.reflect || (sg.ks <= g->H && sg.ks <= g->W), "tconv: reflect padding wider than the plane");
     CAT_REQUIRE((int64_t)g->N * g->H * g->W * sg.xcs < (int64_t)4294967295LL, "tconv: source larger than 2^32 elements");
@@ -1133,25 +644,16 @@ int cat_tconv_fwd(const cat_tconv_t* g, const float* pack, const float* bias, fl
     CAT_REQUIRE(sg.cin > 0 && sg.cin <= sg.c4, "tconv: segment %d valid channel count", s);
     kflops += (double)sg.ks * sg.ks * sg.cin;
   }
-  static const int pw_env = getenv("CAT_TCONV_PW") ? atoi(getenv("CAT_TCONV_PW")) : 0;
-  static const int pw_nt = getenv("CAT_TCONV_PW_NT") ? atoi(getenv("CAT_TCONV_PW_NT")) : 8;
-  // producer-wave kernel: opt-in (CAT_TCONV_PW=1).  Measured on the C2 step (round 3): SLOWER than the register-staged kernel -- teacher
-  // single-segment layers 5.64 -> 6.58 ms, branch sums 6.29 -> 8.13 ms per step -- see DESIGN.md §6; 7 x 7 taps exist only in this variant
-  const bool pw = (pw_env != 0 || hl + hr > 4) && small_src;
-  CAT_REQUIRE(hl + hr <= (pw ? 6 : 4), "tconv: halo %d + %d exceeds the staged patch", hl, hr);
+  CAT_REQUIRE(hl + hr <= 4, "tconv: halo %d + %d exceeds the staged patch", hl, hr);
   static const int tw_env = getenv("CAT_PK_TW") ? atoi(getenv("CAT_PK_TW")) : 0;
   cat_pk::Launch L;
   L.nt_total = cat::cdiv(g->Nn, 16);
-  // N tiles per workgroup (the producer-wave kernel needs <= 128 VGPRs up to 6 tiles, <= 168 at 8: at least two 5-wave workgroups per CU)
-  const int nt_cap = pw ? (pw_nt >= 1 && pw_nt <= 8 ? pw_nt : 8) : 8;
-  L.nblk = cat::cdiv(L.nt_total, nt_cap);
+  L.nblk = cat::cdiv(L.nt_total, 8);
   const int nt = cat::cdiv(L.nt_total, L.nblk);
   L.nblk = cat::cdiv(L.nt_total, nt);
   // 8 x 16 pixel tiles unless that makes a very large grid (then 8 x 32: half the halo traffic, twice the filter reuse per wave)
   const int64_t wg16 = (int64_t)g->N * cat::cdiv(g->Ho, 8) * cat::cdiv(g->Wo, 16) * L.nblk;
-  const int halo = hl + hr > 4 ? 6 : 4;
-  CAT_REQUIRE(halo == 4 || narrow_src, "tconv: 7 x 7 taps are built for sources of <= 4 channels (the image stem)");
-  const int tw = (g->stats || halo == 6) ? 16 : (tw_env ? tw_env : (wg16 >= 4096 ? 32 : 16));
+  const int tw = g->stats ? 16 : (tw_env ? tw_env : (wg16 >= 4096 ? 32 : 16));
   CAT_REQUIRE(tw == 16 || tw == 32, "tconv: CAT_PK_TW must be 16 or 32");
   CAT_REQUIRE(g->stats == nullptr || (g->act == CAT_ACT_NONE && g->res == nullptr && g->scs >= g->ycw), "tconv: statistics need a plain epilogue");
   L.hl = hl;
@@ -1161,8 +663,7 @@ int cat_tconv_fwd(const cat_tconv_t* g, const float* pack, const float* bias, fl
   L.tiles = L.tiles_x * cat::cdiv(g->Ho, cat_pk::TH);
   const int64_t grid = (int64_t)g->N * L.tiles * L.nblk;
   CAT_REQUIRE(grid < (int64_t)2147483647, "tconv: grid too large");
-  const int tabn = (pw && halo == 6) ? 256 : cat_pk::TABN;
-  const size_t lds = (size_t)2 * L.tr * L.tc * cat_pk::PITCH * sizeof(float) + 2 * tabn * sizeof(int) +
+  const size_t lds = (size_t)2 * L.tr * L.tc * cat_pk::PITCH * sizeof(float) + 2 * cat_pk::TABN * sizeof(int) +
                      (g->stats ? (size_t)8 * nt * 16 * sizeof(float) : 0);
   CAT_REQUIRE(lds <= 96 * 1024, "tconv: %zu bytes of LDS (max 96 KB)", lds);
   hipStream_t s = (hipStream_t)stream;
@@ -1173,32 +674,20 @@ int cat_tconv_fwd(const cat_tconv_t* g, const float* pack, const float* bias, fl
     cat::lds_optin(optin, (const void*)cat_pk::tconv_kernel<NT, TW>, 96 * 1024);                                           \
     cat_pk::tconv_kernel<NT, TW><<<(int)grid, 256, lds, s>>>(*g, pack, bias, y, L);                                        \
   }
-#define CAT_PW_LAUNCH(NT, TW, HALO, QPP)                                                                                   \
-  {                                                                                                                        \
-    static cat::LdsOptIn optin;                                                                                            \
-    cat::lds_optin(optin, (const void*)cat_pk::tconv_pw_kernel<NT, TW, HALO, QPP>, 96 * 1024);                           \
-    cat_pk::tconv_pw_kernel<NT, TW, HALO, QPP><<<(int)grid, 320, lds, s>>>(*g, pack, bias, y, L);                        \
+#define CAT_PK_NT(TW)                          \
+  switch (nt) {                                \
+    case 1: CAT_PK_LAUNCH(1, TW) break;        \
+    case 2: CAT_PK_LAUNCH(2, TW) break;        \
+    case 3: CAT_PK_LAUNCH(3, TW) break;        \
+    case 4: CAT_PK_LAUNCH(4, TW) break;        \
+    case 5: CAT_PK_LAUNCH(5, TW) break;        \
+    case 6: CAT_PK_LAUNCH(6, TW) break;        \
+    case 7: CAT_PK_LAUNCH(7, TW) break;        \
+    default: CAT_PK_LAUNCH(8, TW) break;       \
   }
-#define CAT_PK_NT(M, ...)                         \
-  switch (nt) {                                   \
-    case 1: M(1, __VA_ARGS__) break;              \
-    case 2: M(2, __VA_ARGS__) break;              \
-    case 3: M(3, __VA_ARGS__) break;              \
-    case 4: M(4, __VA_ARGS__) break;              \
-    case 5: M(5, __VA_ARGS__) break;              \
-    case 6: M(6, __VA_ARGS__) break;              \
-    case 7: M(7, __VA_ARGS__) break;              \
-    default: M(8, __VA_ARGS__) break;             \
-  }
-  if (pw && tw == 16) {
-    if (halo == 6) { CAT_PK_NT(CAT_PW_LAUNCH, 16, 6, 1) }
-    else { CAT_PK_NT(CAT_PW_LAUNCH, 16, 4, 4) }
-  } else {
-    if (tw == 16) { CAT_PK_NT(CAT_PK_LAUNCH, 16) } else { CAT_PK_NT(CAT_PK_LAUNCH, 32) }
-  }
+  if (tw == 16) { CAT_PK_NT(16) } else { CAT_PK_NT(32) }
 #undef CAT_PK_NT
 #undef CAT_PK_LAUNCH
-#undef CAT_PW_LAUNCH
   return cat::check_launch("tconv_fwd");
 }
 
@@ -1231,12 +720,9 @@ int cat_tstage1_fwd(const cat_tstage1_t* g, const float* x, const float* const* 
   const size_t lds = (size_t)2 * a.tr * a.tc * cat_pk::PITCH * sizeof(float) + 6 * cat_pk::TABN * sizeof(int) + (size_t)8 * nmax * 16 * sizeof(float);
   hipStream_t s = (hipStream_t)stream;
   cat::ProfScope prof("conv_tstage1", 2.0 * (double)g->N * g->H * g->W * g->cin * kflops, 0.0, stream);
-  static const int pw_env = getenv("CAT_TCONV_PW") ? atoi(getenv("CAT_TCONV_PW")) : 0;
-  const bool pw = pw_env != 0 && (int64_t)g->N * g->H * g->W * g->xcs * 4 < (int64_t)2147483647LL;
 #define CAT_S1(NA, NB, NC)                                                                        \
   if (nt[0] == NA && nt[1] == NB && nt[2] == NC) {                                                \
-    if (pw) cat_pk::tstage1_pw_kernel<NA, NB, NC><<<(int)grid, 320, lds, s>>>(a);                 \
-    else cat_pk::tstage1_kernel<NA, NB, NC><<<(int)grid, 256, lds, s>>>(a);                       \
+    cat_pk::tstage1_kernel<NA, NB, NC><<<(int)grid, 256, lds, s>>>(a);                            \
     return cat::check_launch("tstage1_fwd");                                                      \
   }
   CAT_S1(1, 1, 2) CAT_S1(1, 1, 3) CAT_S1(1, 1, 4) CAT_S1(2, 1, 2) CAT_S1(2, 1, 3) CAT_S1(2, 1, 4)

@@ -303,7 +303,6 @@ def _nchw(t):
 # ---------------------------------------------------------------------------------------------- convolutions
 _TCONV = os.environ.get('CAT_TCONV', '1') != '0'      # LDS-tile kernels with packed filters for stride-1 3x3 / 5x5 layers (A/B switch)
 _TCONV_MIN_TILES = int(os.environ.get('CAT_TCONV_MIN_TILES', '96'))
-_STEM_TCONV = os.environ.get('CAT_STEM_TCONV', '1') != '0'     # the 7x7 image stem on the LDS-tile kernel (A/B switch)
 
 
 def set_tconv_min_tiles(n):
@@ -319,9 +318,7 @@ def tconv_applicable(n, h, w, cout, kh, kw, stride, pad, cin=None):
     input gradient); tiny planes (the SPADE generators' 4x8 .. 16x32 stages) keep the split-K im2col kernels, Cout <= 3 the direct ones.
     Wide layers the direct-to-LDS 128 x 128 x 32 GEMM tiles accept (reduction channels % 32 == 0, more than 96 output channels: e.g. the
     256 -> 256 3x3 convs of a resnet generator) stay on those: their matrix pipe runs 0.9 busy against 0.75-0.8 for the LDS-tile kernel."""
-    if not _TCONV or stride != 1 or kh != kw or kh not in (3, 5, 7) or pad != (kh - 1) // 2 or cout <= 3:
-        return False
-    if kh == 7 and not (_STEM_TCONV and cin is not None and cin <= 4):      # 7 x 7 taps: the image stem (3 -> ngf) only
+    if not _TCONV or stride != 1 or kh != kw or kh not in (3, 5) or pad != (kh - 1) // 2 or cout <= 3:
         return False
     if cin is not None and cin % 32 == 0 and cout > 96:
         return False
