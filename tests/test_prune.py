@@ -104,3 +104,38 @@ def test_load_pretrained_weight_bit_exact():
     for key in g.files:
         if key.startswith('B:'):
             np.testing.assert_array_equal(sd[key[2:]].numpy(), g[key])
+
+
+def test_load_pretrained_weight_spade_bit_exact():
+    """The `inception_spade` branch of load_pretrained_weight (reference utils/weight_transfer.py:137-212, 267-288) against the reference's
+    own run (tests/golden/spade_weight_transfer.npz, ngf 8 -> 6): shapes after the transfer -- including the gamma|beta convolutions the
+    reference cuts down to their gamma rows -- and exact fingerprints of all 1062 student tensors."""
+    import json
+    from argparse import Namespace
+    from cat_amd import networks
+    from cat_amd.weight_transfer import load_pretrained_weight
+    g = H.load('spade_weight_transfer.npz')
+    o = json.loads(str(g['opt']))
+
+    def G(ngf):
+        opt = Namespace(**o)
+        opt.ngf, opt.norm_G, opt.gpu_ids = ngf, 'spadesyncbatch3x3', []
+        return networks.define_G(opt.input_nc, 3, ngf, 'inception_spade', 'instance', 0, 'xavier', 0.02, [], opt=opt)
+    A, B = G(8), G(6)
+    assert [[k, list(v.shape)] for k, v in A.state_dict().items()] == json.loads(str(g['A_shapes']))
+    assert [[k, list(v.shape)] for k, v in B.state_dict().items()] == json.loads(str(g['B_shapes_before']))
+    A.load_state_dict(detfill.fill_state_dict(A.state_dict(), 601, gamma_abs_normal=True))
+    B.load_state_dict(detfill.fill_state_dict(B.state_dict(), 602))
+    load_pretrained_weight('inception_spade', 'inception_spade', A, B, 8, 6)
+    sd = B.state_dict()
+    after = json.loads(str(g['B_shapes_after']))
+    assert [[k, list(v.shape)] for k, v in sd.items()] == after
+    assert sum(1 for a, b in zip(json.loads(str(g['B_shapes_before'])), after) if a != b) == 84
+    for (k, v), ref in zip(sd.items(), g['B_fingerprints']):
+        d = v.double().reshape(-1)
+        w = torch.arange(1, d.numel() + 1, dtype=torch.float64)
+        got = np.array([float(d.sum()), float((d * w).sum()), float((d * d).sum())])
+        assert np.array_equal(got, ref), (k, got, ref)
+    for key in g.files:
+        if key.startswith('B:'):
+            np.testing.assert_array_equal(sd[key[2:]].numpy(), g[key])

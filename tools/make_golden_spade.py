@@ -220,7 +220,7 @@ def main():
     print('n_macs T/S', int(out['T_n_macs']), int(out['S_n_macs']))
 
 
-if __name__ == '__main__':
+if __name__ == '__main__' and os.environ.get('GOLDEN_STEP', '1') == '1':
     main()
 
 
@@ -257,6 +257,42 @@ def shrink_golden():
         out['opt'] = json.dumps({k: v for k, v in vars(opt).items() if isinstance(v, (int, float, str, bool, list, type(None)))})
         print('shrink', tag, thr, int(S.n_macs), cfg['fc'], cfg['blocks']['up_1'])
     np.savez_compressed(os.path.join(OUT, 'spade_shrink.npz'), **out)
+
+
+def weight_transfer_golden():
+    """load_pretrained_weight('inception_spade', ...) (utils/weight_transfer.py:137-212, 267-288) run for real: ngf 8 -> 6, seeded weights.
+    Recorded: every student tensor's shape AFTER the transfer (the reference replaces the gamma|beta convs by their gamma rows) and exact
+    fingerprints of all tensors; five tensors in full."""
+    from utils.weight_transfer import load_pretrained_weight
+    opt = spade_opt(data_height=128, data_width=256, data_channel=6)
+    def G(ngf):
+        o = copy.deepcopy(opt)
+        o.ngf, o.norm_G = ngf, 'spadesyncbatch3x3'
+        return networks.define_G(opt.input_nc, 3, ngf, 'inception_spade', 'instance', 0, 'xavier', 0.02, [], opt=o)
+    A, B = G(8), G(6)
+    A.load_state_dict(detfill.fill_state_dict(A.state_dict(), 601, gamma_abs_normal=True))
+    B.load_state_dict(detfill.fill_state_dict(B.state_dict(), 602))
+    out = {'A_shapes': shapes_json(A.state_dict()), 'B_shapes_before': shapes_json(B.state_dict())}
+    load_pretrained_weight('inception_spade', 'inception_spade', A, B, 8, 6)
+    sd = B.state_dict()
+    out['B_shapes_after'] = shapes_json(sd)
+    fp = []
+    for k, v in sd.items():
+        d = v.double().reshape(-1)
+        w = torch.arange(1, d.numel() + 1, dtype=torch.float64)
+        fp.append([float(d.sum()), float((d * w).sum()), float((d * d).sum())])
+    out['B_fingerprints'] = np.array(fp, dtype=np.float64)
+    for k in ('fc.weight', 'fc_norm.weight', 'head_0.spade.res_ops.1.0.conv.weight', 'head_0.spade.res_ops.1.1.weight', 'up_1.shortcut.1.conv.weight',
+              'up_1.res_ops.1.0.conv.weight', 'conv_img.weight'):
+        out['B:' + k] = sd[k].numpy().copy()
+    out['opt'] = json.dumps({k: v for k, v in vars(opt).items() if isinstance(v, (int, float, str, bool, list, type(None)))})
+    np.savez_compressed(os.path.join(OUT, 'spade_weight_transfer.npz'), **out)
+    changed = sum(1 for (k, a), (_, b) in zip(json.loads(out['B_shapes_before']), json.loads(out['B_shapes_after'])) if a != b)
+    print('spade_weight_transfer.npz', len(sd), 'tensors,', changed, 'changed shape')
+
+
+if __name__ == '__main__' and os.environ.get('GOLDEN_TRANSFER', '1') == '1':
+    weight_transfer_golden()
 
 
 if __name__ == '__main__' and os.environ.get('GOLDEN_SHRINK', '1') == '1':
