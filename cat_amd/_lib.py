@@ -58,7 +58,7 @@ class PrepJob(C.Structure):
 
 
 PAD_ZERO, PAD_REFLECT = 0, 1
-ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, ACT_RELU6 = 0, 1, 2, 3, 4
 NORM_INSTANCE, NORM_BATCH = 0, 1
 LOSS_L1, LOSS_LSGAN, LOSS_HINGE_D_REAL, LOSS_HINGE_D_FAKE, LOSS_NEG_MEAN, LOSS_MSE, LOSS_BCE_LOGITS, LOSS_MEAN = range(8)
 

@@ -68,6 +68,7 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
     case CAT_ACT_RELU: return v > 0.f ? v : 0.f;
     case CAT_ACT_LRELU: return v > 0.f ? v : v * slope;
     case CAT_ACT_TANH: return tanhf(v);
+    case CAT_ACT_RELU6: return fminf(fmaxf(v, 0.f), 6.f);
     default: return v;
   }
 }
@@ -78,6 +79,7 @@ __device__ __forceinline__ float act_grad_from_out(float y, int act, float slope
     case CAT_ACT_RELU: return y > 0.f ? 1.f : 0.f;
     case CAT_ACT_LRELU: return y > 0.f ? 1.f : slope;
     case CAT_ACT_TANH: return 1.f - y * y;
+    case CAT_ACT_RELU6: return (y > 0.f && y < 6.f) ? 1.f : 0.f;      // hardtanh_backward: 0 at and beyond both bounds
     default: return 1.f;
   }
 }

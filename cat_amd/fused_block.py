@@ -70,6 +70,9 @@ def applicable(block, x):
         return False
     if kind is cnn.InstanceNorm2d and any(m.track_running_stats for m in norms):
         return False
+    first_act = block.res_ops[0][1][2] if len(block.res_ops) else block.dw_ops[0][0][2]
+    if cnn._act_code(first_act)[0] not in (L.ACT_RELU, L.ACT_LRELU):     # the staging paths apply ReLU / LeakyReLU only (nn.ReLU6: general path)
+        return False
     ks = [op[1][0].kernel_size[0] for op in block.res_ops] + [op[2][0].kernel_size[0] for op in block.dw_ops]
     if any(k not in (1, 3, 5) for k in ks):
         return False

@@ -22,8 +22,9 @@ def add_prefix(name, prefix=None, split='.'):
 
 
 def get_active_fn(name):
-    """reference inception_modules.py:12-19 (ReLU6 is never selected by the distillation scripts)."""
+    """reference inception_modules.py:12-19."""
     active_fn = {
+        'nn.ReLU6': functools.partial(cnn.ReLU6, inplace=True),
         'nn.ReLU': functools.partial(cnn.ReLU, inplace=True),
         'nn.LeakyReLU': functools.partial(cnn.LeakyReLU, inplace=True),
     }[name]

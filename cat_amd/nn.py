@@ -28,6 +28,8 @@ def _act_code(m):
         return L.ACT_NONE, 0.0
     if isinstance(m, nn.LeakyReLU):
         return L.ACT_LRELU, float(m.negative_slope)
+    if isinstance(m, nn.ReLU6):
+        return L.ACT_RELU6, 0.0
     if isinstance(m, nn.ReLU):
         return L.ACT_RELU, 0.0
     if isinstance(m, nn.Tanh):
@@ -55,7 +57,11 @@ class Tanh(_Act, nn.Tanh):
     pass
 
 
-_ACTS = (ReLU, LeakyReLU, Tanh)
+class ReLU6(_Act, nn.ReLU6):
+    pass
+
+
+_ACTS = (ReLU, LeakyReLU, Tanh, ReLU6)
 
 
 class Identity(nn.Module):

@@ -25,7 +25,7 @@ extern "C" {
 typedef void* cat_stream_t; /* hipStream_t */
 
 enum { CAT_PAD_ZERO = 0, CAT_PAD_REFLECT = 1 };
-enum { CAT_ACT_NONE = 0, CAT_ACT_RELU = 1, CAT_ACT_LRELU = 2, CAT_ACT_TANH = 3 };
+enum { CAT_ACT_NONE = 0, CAT_ACT_RELU = 1, CAT_ACT_LRELU = 2, CAT_ACT_TANH = 3, CAT_ACT_RELU6 = 4 /* nn.ReLU6: min(max(x, 0), 6) */ };
 enum { CAT_NORM_INSTANCE = 0, CAT_NORM_BATCH = 1 };
 
 const char* cat_hip_last_error(void);

@@ -263,11 +263,11 @@ def test_depthwise_conv(dev, c, k, reflect, n, h, w):
 
 @pytest.mark.parametrize('mode,c,n,h,w,act', [('instance', 54, 2, 16, 16, 1), ('instance', 7, 3, 9, 5, 1), ('batch', 77, 4, 8, 8, 1),
                                               ('batch', 256, 2, 6, 6, 2), ('instance', 1024, 1, 5, 5, 2), ('batch', 16, 2, 64, 64, 0),
-                                              ('instance', 1100, 1, 4, 4, 0)])
+                                              ('instance', 1100, 1, 4, 4, 0), ('batch', 42, 3, 10, 12, 4), ('instance', 19, 2, 9, 9, 4)])
 def test_norm_fwd_bwd(dev, mode, c, n, h, w, act):
     from cat_amd import ops, _lib as L
     x = detfill.normal((n, c, h, w), 13) * 2.0 + 3.0      # non-zero mean: exercises the shifted-sum variance
-    ga = 1.0 + 0.2 * detfill.normal((c,), 14)
+    ga = (3.0 if act == 4 else 1.0) * (1.0 + 0.2 * detfill.normal((c,), 14))
     be = 0.1 * detfill.normal((c,), 15)
     xr, gr, br = x.clone().requires_grad_(True), ga.clone().requires_grad_(True), be.clone().requires_grad_(True)
     rm, rv = torch.zeros(c), torch.ones(c)
@@ -275,7 +275,10 @@ def test_norm_fwd_bwd(dev, mode, c, n, h, w, act):
         yr = F.instance_norm(xr, None, None, gr, br, True, 0.1, 1e-5)
     else:
         yr = F.batch_norm(xr, rm, rv, gr, br, True, 0.1, 1e-5)
-    yr = F.relu(yr) if act == 1 else (F.leaky_relu(yr, 0.2) if act == 2 else yr)
+    if act == 4:      # nn.ReLU6 (get_active_fn('nn.ReLU6'), reference inception_modules.py:12-19): scale so that both bounds are hit
+        yr = F.relu6(yr)
+    else:
+        yr = F.relu(yr) if act == 1 else (F.leaky_relu(yr, 0.2) if act == 2 else yr)
     gy = detfill.normal(tuple(yr.shape), 16)
     yr.backward(gy)
     xg = _nhwc(x, dev, True)
