@@ -427,7 +427,15 @@ def student_forward_rate(model, batch, spade, graph=True):
             'batch': int(x.shape[0])}
 
 
-PMC_FILE = 'profiles/r02_pmc_hbm.json'
+PROFILE_TAG = 'r03'
+PMC_FILE = f'profiles/{PROFILE_TAG}_pmc_hbm.json'
+STATS_FILE = f'profiles/{PROFILE_TAG}_kernel_stats_c2.txt'
+META_FILE = f'profiles/{PROFILE_TAG}_meta.json'          # {"commit": ..., "date": ...}: the tree the committed profiles were taken from
+
+
+def _profile_commit():
+    path = os.path.join(ROOT, META_FILE)
+    return json.load(open(path)).get('commit') if os.path.exists(path) else None
 
 
 def pmc_traffic(family):
@@ -442,6 +450,23 @@ def pmc_traffic(family):
     for k, v in table.items():
         if k.startswith(base + '_kernel'):
             return v.get('hbm_bytes_per_launch')
+    return None
+
+
+def rocprof_avg_us(family):
+    """Average launch duration (us) of the dominant kernel in the committed `rocprofv3 --kernel-trace --stats` summary of this command."""
+    path = os.path.join(ROOT, STATS_FILE)
+    if not os.path.exists(path):
+        return None
+    base = family.rsplit('_', 1)[0] + '_kernel'
+    for line in open(path):
+        if line.startswith('#') or base not in line:
+            continue
+        cols = line.split()
+        try:
+            return float(cols[-3])       # ... calls total_us avg_us pct us/step
+        except (ValueError, IndexError):
+            continue
     return None
 
 
@@ -485,10 +510,19 @@ def kernel_roofline(model, step, args):
     tot_gf = sum(v['gflop_per_step'] for v in conv.values())
     d = conv[dom]
     achieved = d['gflop_per_step'] / d['ms_per_step'] if d['ms_per_step'] > 0 else 0.0   # GFLOP/ms == TFLOP/s
+    headline = getattr(args, 'workload', 'c2') == 'c2' and args.size == 256 and args.batch == 16
+    avg_us = 1e3 * d['ms_per_step'] / max(d['launches_per_step'], 1)
+    rp_us = rocprof_avg_us(dom) if headline else None
+    gflop_launch = d['gflop_per_step'] / max(d['launches_per_step'], 1)
     return {'bound': 'mfma', 'kernel': dom, 'achieved': round(achieved, 3), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-            'frac': round(achieved / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': pmc_traffic(dom) if (getattr(args, 'workload', 'c2') == 'c2' and args.size == 256 and args.batch == 16) else None,
+            'frac': round(achieved / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': pmc_traffic(dom) if headline else None,
             'traffic_source': PMC_FILE + ' (separate rocprofv3 --pmc passes of this command; not a same-run measurement)',
-            'avg_launch_us': round(1e3 * d['ms_per_step'] / max(d['launches_per_step'], 1), 3),
+            'avg_launch_us': round(avg_us, 3),
+            # the same fraction from the committed rocprofv3 --kernel-trace --stats summary (its average launch duration of this kernel):
+            # HIP events see the kernel alone, rocprof's span includes dispatch overhead -- the two bracket the truth (~3 % apart)
+            'rocprof': None if rp_us is None else {'avg_launch_us': rp_us, 'achieved': round(1e3 * gflop_launch / rp_us, 3),
+                                                   'frac': round(1e3 * gflop_launch / rp_us / MFMA_F32_PEAK_TFLOPS, 4), 'source': STATS_FILE},
+            'profiles_commit': _profile_commit(),
             'all_conv': {'achieved': round(tot_gf / tot_ms, 3) if tot_ms else 0.0, 'ms_per_step': round(tot_ms, 3),
                          'gflop_per_step': round(tot_gf, 2)},
             'families': {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in fams.items()}}
