@@ -95,6 +95,8 @@ SIGNATURES = {
     'cat_dwconv2d_wgrad': (c_i, [_G, c_p, c_p, c_p, c_i, c_p, c_p]),
     'cat_dwconv2d_wgrad_ws_bytes': (C.c_size_t, [_G]),
     'cat_reflect_pad_bwd': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    'cat_replicate_pad_fwd': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    'cat_replicate_pad_bwd': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     'cat_channel_sum': (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p]),
     'cat_channel_sum_ws_bytes': (C.c_size_t, [c_i, c_i]),
     'cat_norm_ws_bytes': (C.c_size_t, [_NG]),

@@ -225,9 +225,66 @@ __global__ __launch_bounds__(256) void reflect_fold_kernel(const float* __restri
   }
 }
 
+// nn.ReplicationPad2d(pad) (reference inception_modules.py:114-115, padding_type='replicate'): the padded copy is materialised (the option is
+// not used by any launch script; the convolution behind it then runs with padding 0) and its backward folds the clamped positions
+__global__ __launch_bounds__(256) void replicate_pad_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int cs,
+                                                                int pad) {
+  const int nq = cs / 4;
+  const int Hp = H + 2 * pad, Wp = W + 2 * pad;
+  const int64_t total = (int64_t)N * Hp * Wp * nq;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int cq = (int)(i % nq);
+    int64_t r = i / nq;
+    const int xp = (int)(r % Wp);
+    r /= Wp;
+    const int yp = (int)(r % Hp);
+    const int n = (int)(r / Hp);
+    const int ys = min(max(yp - pad, 0), H - 1), xs = min(max(xp - pad, 0), W - 1);
+    *reinterpret_cast<f4*>(y + i * 4) = *reinterpret_cast<const f4*>(x + (((int64_t)n * H + ys) * W + xs) * cs + cq * 4);
+  }
+}
+
+// dx[n, y, x] = sum of dyp over the padded positions that clamp onto (y, x): one row / column in the interior, pad + 1 of them on a border
+__global__ __launch_bounds__(256) void replicate_pad_bwd_kernel(const float* __restrict__ dyp, float* __restrict__ dx, int N, int H, int W, int cs,
+                                                                int pad) {
+  const int nq = cs / 4;
+  const int Wp = W + 2 * pad, Hp = H + 2 * pad;
+  const int64_t total = (int64_t)N * H * W * nq;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int cq = (int)(i % nq);
+    int64_t r = i / nq;
+    const int xw = (int)(r % W);
+    r /= W;
+    const int yh = (int)(r % H);
+    const int n = (int)(r / H);
+    const int y0 = yh == 0 ? 0 : yh + pad, y1 = yh == H - 1 ? Hp - 1 : yh + pad;     // H == 1: the single row collects all of them
+    const int x0 = xw == 0 ? 0 : xw + pad, x1 = xw == W - 1 ? Wp - 1 : xw + pad;
+    f4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int a = y0; a <= y1; ++a)
+      for (int b = x0; b <= x1; ++b) s += *reinterpret_cast<const f4*>(dyp + (((int64_t)n * Hp + a) * Wp + b) * cs + cq * 4);
+    *reinterpret_cast<f4*>(dx + i * 4) = s;
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+int cat_replicate_pad_fwd(const float* x, float* y, int N, int H, int W, int C, int cs, int pad, cat_stream_t stream) {
+  cat::ProfScope prof("elementwise", 0.0, 8.0 * N * (H + 2 * pad) * (W + 2 * pad) * cs, stream);
+  CAT_REQUIRE(cs % 4 == 0 && cs >= C && pad >= 0 && N > 0 && H > 0 && W > 0, "replicate_pad_fwd: bad geometry");
+  const int64_t total = (int64_t)N * (H + 2 * pad) * (W + 2 * pad) * (cs / 4);
+  replicate_pad_fwd_kernel<<<ew_grid(total), 256, 0, (hipStream_t)stream>>>(x, y, N, H, W, cs, pad);
+  return cat::check_launch("replicate_pad_fwd");
+}
+
+int cat_replicate_pad_bwd(const float* dyp, float* dx, int N, int H, int W, int C, int cs, int pad, cat_stream_t stream) {
+  cat::ProfScope prof("elementwise", 0.0, 8.0 * N * (H + 2 * pad) * (W + 2 * pad) * cs, stream);
+  CAT_REQUIRE(cs % 4 == 0 && cs >= C && pad >= 0 && N > 0 && H > 0 && W > 0, "replicate_pad_bwd: bad geometry");
+  const int64_t total = (int64_t)N * H * W * (cs / 4);
+  replicate_pad_bwd_kernel<<<ew_grid(total), 256, 0, (hipStream_t)stream>>>(dyp, dx, N, H, W, cs, pad);
+  return cat::check_launch("replicate_pad_bwd");
+}
 
 int cat_act_fwd(const float* x, float* y, int64_t n, int act, float slope, cat_stream_t stream) {
   cat::ProfScope prof("elementwise", 0.0, 8.0 * n, stream);

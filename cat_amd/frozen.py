@@ -50,6 +50,8 @@ def applicable(block, x):
     norms = [op[1][1] for op in block.res_ops] + [op[0][1] for op in block.dw_ops] + [op[2][1] for op in block.dw_ops] + [block.pw_bn]
     if not all(_foldable(n) for n in norms):
         return False
+    if block.padding_type not in ('reflect', 'zero'):      # 'replicate' is a materialised pad: general path
+        return False
     return block.dropout_rate == 0 and len(block.dw_ops) + sum(1 for op in block.res_ops if op[1][0].kernel_size[0] == 1) >= 2
 
 

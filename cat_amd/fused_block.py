@@ -53,7 +53,7 @@ def _has_hooks(mod):
 
 
 def applicable(block, x):
-    if not _ENABLED or not block.training or not x.is_cuda or block.dropout_rate != 0:
+    if not _ENABLED or not block.training or not x.is_cuda or block.dropout_rate != 0 or block.padding_type not in ('reflect', 'zero'):
         return False
     if torch.is_grad_enabled() and not _BACKWARD_READY:
         return False

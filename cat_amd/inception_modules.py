@@ -83,6 +83,8 @@ class InvertedResidualChannels(nn.Module):
 
         if self.padding_type == 'reflect':
             self.pad = cnn.ReflectionPad2d
+        elif self.padding_type == 'replicate':
+            self.pad = cnn.ReplicationPad2d
         elif self.padding_type == 'zero':
             self.pad = functools.partial(cnn.ZeroPad2d, value=0.0)
         else:

@@ -88,6 +88,19 @@ class ReflectionPad2d(nn.ReflectionPad2d):
         return Padded(x, p, L.PAD_REFLECT) if p > 0 else x
 
 
+class ReplicationPad2d(nn.ReplicationPad2d):
+    """padding_type='replicate' (reference inception_modules.py:114-115): unlike the reflect / zero paddings this one is not folded into
+    the next convolution's gather -- the padded copy is written (the option is not used by any launch script)."""
+
+    def forward(self, x):
+        p = self.padding[0]
+        if any(q != p for q in self.padding):
+            raise NotImplementedError('only symmetric replication padding is supported')
+        if isinstance(x, Padded):
+            raise NotImplementedError('stacked paddings')
+        return ops.ReplicatePadFn.apply(x, p) if p > 0 else x
+
+
 class ZeroPad2d(nn.ConstantPad2d):
     def __init__(self, padding, value=0.0):
         super().__init__(padding, value)

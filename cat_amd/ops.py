@@ -667,6 +667,28 @@ class ActFn(torch.autograd.Function):
         return _act_bwd(y, conform(dy), ctx.act, ctx.slope), None, None
 
 
+class ReplicatePadFn(torch.autograd.Function):
+    """nn.ReplicationPad2d(pad): materialised (reference inception_modules.py:114-115; no launch script selects it)."""
+
+    @staticmethod
+    def forward(ctx, x, pad):
+        _require_cuda(x)
+        x = conform(x)
+        n, c, h, w = x.shape
+        y = empty_act(n, c, h + 2 * pad, w + 2 * pad, x.device, act_cs(x))
+        L.call('cat_replicate_pad_fwd', _p(x), _p(y), n, h, w, c, act_cs(x), pad, _stream())
+        ctx.dims = (n, c, h, w, pad)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        n, c, h, w, pad = ctx.dims
+        dy = conform(dy)
+        dx = empty_act(n, c, h, w, dy.device, act_cs(dy))
+        L.call('cat_replicate_pad_bwd', _p(dy), _p(dx), n, h, w, c, act_cs(dy), pad, _stream())
+        return dx, None
+
+
 class AddNFn(torch.autograd.Function):
     """sum of k same-shaped activations (branch sum + residual of InvertedResidualChannels)."""
 

@@ -94,6 +94,11 @@ size_t cat_dwconv2d_wgrad_ws_bytes(const cat_conv_t* g);
 int cat_reflect_pad_bwd(const float* dxp, float* dx, int N, int H, int W, int C, int cs, int pad,
                         cat_stream_t stream);
 
+/* nn.ReplicationPad2d(pad) (reference models/modules/inception_modules.py:114-115, padding_type='replicate'): y[N,H+2p,W+2p,C] with the border
+ * pixels repeated, and its backward (dx gathers the padded positions that clamp onto each source pixel). */
+int cat_replicate_pad_fwd(const float* x, float* y, int N, int H, int W, int C, int cs, int pad, cat_stream_t stream);
+int cat_replicate_pad_bwd(const float* dyp, float* dx, int N, int H, int W, int C, int cs, int pad, cat_stream_t stream);
+
 /* Per-channel sums over pixels: out[c] (+)= sum_m x[m*cs + c]  (conv bias gradient). */
 int cat_channel_sum(const float* x, int M, int C, int cs, float* out, int accumulate, void* ws, cat_stream_t stream);
 size_t cat_channel_sum_ws_bytes(int M, int cs);

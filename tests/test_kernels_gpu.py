@@ -445,3 +445,63 @@ def test_integration_md_stub_runs_verbatim(dev):
     got = y[..., :5].permute(0, 3, 1, 2).cpu()
     assert rel(got, ref) < TOL
     assert float(y[..., 5:].abs().max()) == 0.0                      # padding channels are written as zeros
+
+
+@pytest.mark.parametrize('pad,n,c,h,w', [(1, 2, 11, 9, 7), (2, 1, 42, 6, 10), (2, 3, 4, 1, 5)])
+def test_replication_pad(dev, pad, n, c, h, w):
+    """padding_type='replicate' (reference inception_modules.py:114-115): forward copy and backward fold against F.pad."""
+    from cat_amd import ops
+    x = detfill.normal((n, c, h, w), 301)
+    xr = x.clone().requires_grad_(True)
+    yr = F.pad(xr, (pad, pad, pad, pad), mode='replicate')
+    gy = detfill.normal(tuple(yr.shape), 302)
+    yr.backward(gy)
+    xg = _nhwc(x, dev, True)
+    y = ops.ReplicatePadFn.apply(xg, pad)
+    assert tuple(y.shape) == tuple(yr.shape) and torch.equal(y.detach().cpu(), yr.detach())
+    y.backward(_nhwc(gy, dev))
+    assert rel(xg.grad, xr.grad) < 1e-6
+
+
+def test_block_with_replicate_padding_and_relu6(dev):
+    """InvertedResidualChannels(padding_type='replicate', active_fn=nn.ReLU6) -- two reference options no launch script selects -- run
+    the general per-layer path and match stock torch (forward and input gradient)."""
+    import functools
+    from torch import nn
+    from cat_amd import fused_block, nn as cnn, ops
+    from cat_amd.inception_modules import InvertedResidualChannels, get_active_fn
+    C, res, dw = 20, [6, 0, 5], [4, 7, 0]
+    blk = InvertedResidualChannels(C, res, dw, 1, [1, 3, 5], [1, 3, 5], padding_type='replicate', use_bias=False, norm_layer=cnn.BatchNorm2d,
+                                   norm_kwargs={'momentum': 0.1, 'eps': 1e-5}, active_fn=get_active_fn('nn.ReLU6'))
+    sd = detfill.fill_state_dict(blk.state_dict(), 311, gamma_abs_normal=True)
+    for k in sd:
+        if k.endswith('.weight') and sd[k].dim() == 1:
+            sd[k] = sd[k] * 4.0          # wide pre-activations: both bounds of ReLU6 are hit
+    blk.load_state_dict(sd)
+    blk = blk.to(dev).train()
+    x = detfill.normal((2, C, 24, 20), 312)
+    assert not fused_block.applicable(blk, ops.to_nhwc(x.to(dev)))
+    mk = lambda c: nn.BatchNorm2d(c, momentum=0.1, eps=1e-5)
+    res_ops, dw_ops = nn.ModuleList(), nn.ModuleList()
+    for m, k in zip(res, [1, 3, 5]):
+        if m:
+            res_ops.append(nn.Sequential(nn.ReplicationPad2d((k - 1) // 2), nn.Sequential(nn.Conv2d(C, m, k, bias=False), mk(m), nn.ReLU6()), nn.Dropout(0.0),
+                                         nn.ReplicationPad2d((k - 1) // 2), nn.Conv2d(m, C, k, bias=False)))
+    for m, k in zip(dw, [1, 3, 5]):
+        if m:
+            dw_ops.append(nn.Sequential(nn.Sequential(nn.Conv2d(C, m, 1, bias=False), mk(m), nn.ReLU6()), nn.ReplicationPad2d((k - 1) // 2),
+                                        nn.Sequential(nn.Conv2d(m, m, k, groups=m, bias=False), mk(m), nn.ReLU6()), nn.Dropout(0.0),
+                                        nn.Conv2d(m, C, 1, bias=False)))
+    twin = nn.Module()
+    twin.res_ops, twin.dw_ops, twin.pw_bn = res_ops, dw_ops, mk(C)
+    twin.load_state_dict({k: v.clone() for k, v in sd.items()})
+    twin.train()
+    xr = x.clone().requires_grad_(True)
+    yr = xr + twin.pw_bn(sum(op(xr) for op in twin.res_ops) + sum(op(xr) for op in twin.dw_ops))
+    gy = detfill.normal(tuple(yr.shape), 313)
+    yr.backward(gy)
+    xg = _nhwc(x, dev, True)
+    y = blk(xg)
+    assert rel(y, yr) < 1e-4
+    y.backward(_nhwc(gy, dev))
+    assert rel(xg.grad, xr.grad) < 5e-4
