@@ -1981,7 +1981,8 @@ static int conv_dgrad_impl(const cat_conv_t* g, const float* dy, const float* w,
 static int wgrad32d_nsplit(const cat_conv_t* g, int* rows_per) {
   static const int on = getenv("CAT_WGRAD_DIRECT") ? atoi(getenv("CAT_WGRAD_DIRECT")) : 1;
   const int wcs = g->wcs > 0 ? g->wcs : g->Cin;
-  if (!on || g->Cout <= 96 || (g->Cin & 127) || g->pad_mode != CAT_PAD_ZERO || (g->Wo > 32 && (g->Wo & 31)) || cat::smallco_applicable(g) ||
+  static const int ragged = getenv("CAT_WGRAD_RAGGED") ? atoi(getenv("CAT_WGRAD_RAGGED")) : 1;   // output rows that end in a partial 32-pixel segment
+  if (!on || g->Cout <= 96 || (g->Cin & 127) || g->pad_mode != CAT_PAD_ZERO || (!ragged && g->Wo > 32 && (g->Wo & 31)) || cat::smallco_applicable(g) ||
       (int64_t)g->N * g->H * g->W * g->xcs * 4 >= (int64_t)2147483647 || (int64_t)g->N * g->Ho * g->Wo * g->ycs * 4 >= (int64_t)2147483647 ||
       wcs < g->Cin)
     return 0;

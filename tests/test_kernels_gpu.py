@@ -74,6 +74,9 @@ CONV_CASES = [
     (256, 128, 4, 1, 1, False, 0, 2, 11, 32),
     (128, 130, 3, 2, 1, False, 0, 2, 9, 64),
     (512, 1, 4, 1, 2, False, 0, 2, 9, 17),
+    # ... and rows that END in a partial segment (63 and 50 output columns: the 512 x 512 PatchGAN's stride-1 layers)
+    (128, 128, 4, 1, 1, False, 0, 1, 8, 64),
+    (128, 160, 4, 2, 1, False, 2, 1, 10, 100),
     # PatchGAN's first layer: the image gradient through the class-per-wave 4x4 / stride 2 dgrad (3 and 6 channels, ragged and odd planes)
     (3, 64, 4, 2, 1, False, 2, 2, 70, 50),
     (6, 20, 4, 2, 1, False, 0, 1, 33, 37),
