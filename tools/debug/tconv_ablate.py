@@ -1,0 +1,75 @@
+"""Where does tconv_kernel's time go?  Times representative launches under the kernel's diagnostic switches (CAT_PK_ABLATE bits, results
+become wrong, the instruction stream stays the same): 1 = every MFMA group reads the SAME 1 KB filter block per N tile (filter stream from
+L1), 2 = every A fragment reads LDS offset 0 (no bank conflicts), 4 = staging loads hit one cached line (no HBM / L2 patch traffic),
+8 = no staging / barrier after the first chunk.      python tools/debug/tconv_ablate.py"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from cat_amd import _lib as L, ops, tconv  # noqa: E402
+
+dev = torch.device('cuda:0')
+
+
+def timeit(fn, iters=30):
+    for _ in range(5):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / iters
+
+
+def main():
+    L.load()
+    n, h, w = 16, 64, 64
+    cases = []
+    for name, cin, cout, k in [('T 256->42 k5 (NT3)', 256, 42, 5), ('T 42->256 k5 (NT8)', 42, 256, 5), ('T 256->42 k3 (NT3)', 256, 42, 3),
+                               ('S 77->18 k5 (NT2)', 77, 18, 5), ('S 18->77 k5 (NT5)', 18, 77, 5)]:
+        x = ops.to_nhwc(torch.randn(n, cin, h, w, device=dev))
+        wt = ops.padded_weight_like((cout, cin, k, k), dev)
+        wt.copy_(torch.randn(cout, cin, k, k, device=dev))
+        pk = tconv.pack(wt, tconv.FWD)
+        y = ops.empty_act(n, cout, h, w, dev)
+        seg = tconv.Segment(x, k, (k - 1) // 2, True, 0)
+        fl = 2.0 * n * h * w * cout * k * k * cin
+        cases.append((name, fl, (lambda seg=seg, pk=pk, y=y, cout=cout: tconv.run([seg], pk, None, y, cout, n, h, w, h, w, L.ACT_RELU))))
+    ms, kss, cout = [11, 12, 18, 15, 15, 12], [1, 3, 5, 1, 1, 1], 77
+    offs = np.cumsum([0] + [tconv.cs4(m) for m in ms])
+    hc = int(offs[-1])
+    hg = torch.randn(n, h, w, hc, device=dev)
+    scg, shg = torch.rand(hc, device=dev) + 0.5, torch.randn(hc, device=dev) * 0.1
+    packs, segs, poff, fl = [], [], 0, 0.0
+    for bi, (m, k) in enumerate(zip(ms, kss)):
+        wt = ops.padded_weight_like((cout, m, k, k), dev)
+        wt.copy_(torch.randn(cout, m, k, k, device=dev))
+        packs.append(tconv.pack(wt, tconv.FWD))
+        o = int(offs[bi])
+        segs.append(tconv.Segment(hg, k, (k - 1) // 2, True, poff, c4=tconv.cs4(m), scale=scg[o:], shift=shg[o:], act=L.ACT_RELU, xcs=hc,
+                                  ptr=hg.data_ptr() + 4 * o))
+        poff += packs[-1].numel()
+        fl += 2.0 * n * h * w * cout * k * k * m
+    pk = torch.cat(packs)
+    y = ops.empty_act(n, cout, h, w, dev)
+    cases.append(('S branch sum (NT5, 6 seg)', fl, lambda: tconv.run(segs, pk, None, y, cout, n, h, w, h, w)))
+    modes = [0, 1, 2, 4, 8, 3, 12, 15]
+    print('%-28s' % 'launch' + ''.join('%11s' % ('abl=%d' % m) for m in modes) + '    (us; TFLOP/s at abl=0)')
+    with torch.no_grad():
+        for name, fl, fn in cases:
+            row = []
+            for m in modes:
+                os.environ['CAT_PK_ABLATE'] = str(m)
+                row.append(timeit(fn))
+            os.environ['CAT_PK_ABLATE'] = '0'
+            print('%-28s' % name + ''.join('%11.1f' % t for t in row) + '    %.1f TF' % (fl / row[0] / 1e6))
+
+
+if __name__ == '__main__':
+    main()
