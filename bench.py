@@ -276,7 +276,9 @@ def main():
     if args.graph and (dp and not spade and not args.no_overlap or not dp):
         from cat_amd.graph import GraphedDPStep, GraphedStep
         try:
-            seg = (dp or args.segments) and not spade
+            # (the frozen teacher on a side stream INSIDE one captured graph crashes the HIP runtime at capture: --teacher-side-stream with
+            # --graph 1 therefore means the segment schedule, whose teacher graph is replayed on the side stream)
+            seg = (dp or args.segments or args.teacher_side_stream) and not spade
             graphed = (GraphedDPStep if seg else GraphedStep)(model, batches[0])
             launch = ('hipGraph segments%s (teacher on a side stream | student fwd + D bwd | Adam D + G bwd)' % (' around the collectives' if dp else '')) \
                 if seg else 'hipGraph replay'
