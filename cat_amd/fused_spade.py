@@ -1,0 +1,527 @@
+"""Fused training-mode path of the six-branch units of the GauGAN generator (reference models/modules/inception_modules.py:428-505,
+549-562: SPADEInvertedResidualChannels; :648-700, 746-762: the gamma|beta net of InceptionSPADE):
+
+    unit(x) = sum_k conv2_k(relu(bn(conv1_k(x)))) + sum_k pw2_k(relu(bn(dw_k(relu(bn(pw1_k(x))))))) [+ r]
+
+with train-mode (Synchronized)BatchNorm2d in every position, zero ("same") padding, C_in != C_out in general and an optional addend r (the
+block's shortcut).  The per-layer path launches ~45 kernels per unit (12 convs, 9 norms x 3, add_n); most of them HBM-bound passes over
+hidden tensors of 1..13 channels on planes of up to 256 x 512 pixels.  Here a unit is the protocol of cat_amd/fused_block.py without the
+closing pw_bn:
+
+    stage 1   first convs of all branches -> one concatenated pre-norm buffer Z1 + per-tile statistics   (cat_tstage1_fwd / cat_tconv_fwd)
+    finalize  scale / shift of all stage-1 norms + their running statistics                               (cat_tnorm_finalize)
+    dw        all depthwise convs as one launch, norm + ReLU of stage 1 applied while staging             (cat_dwm_fwd)
+    finalize
+    stage 2   the branch sum: six second convs K-concatenated, norm + ReLU applied while staging, bias and the addend r in the epilogue
+
+5 launches, no normalised tensor is ever written.  The backward pass re-materialises the two hidden activations and reuses the kernels of
+the fused inception block (branch-wise weight gradients on side streams, norm backward once per stage over the concatenation, the first-conv
+input gradients as one K-concatenated launch).  Taken when the unit runs in training mode on one rank (with several ranks the
+SynchronizedBatchNorm statistics are exchanged per layer: general path), on planes of at least `ops._TCONV_MIN_TILES` 8 x 16 tiles (the
+64 x 128 .. 256 x 512 stages at batch 4); tests/test_spade_gpu.py::test_fused_spade_units_match_general_path pins it to the general path."""
+import ctypes as C
+import os
+
+import torch
+
+from . import _lib as L
+from . import nn as cnn
+from . import ops
+from . import optim
+from . import tconv
+
+_ENABLED = os.environ.get('CAT_FUSED_SPADE', '1') != '0'
+
+
+def set_enabled(on):
+    global _ENABLED
+    _ENABLED = bool(on)
+
+
+def _cs4(c):
+    return (c + 3) // 4 * 4
+
+
+def _conv_of(m):
+    """nn.Conv2d behind a `Conv` wrapper (main branches) or the plain conv (gamma|beta nets)."""
+    return m.conv if hasattr(m, 'conv') and not isinstance(m, cnn.Conv2d) else m
+
+
+def _branches(res_ops, dw_ops):
+    res = [dict(kind='res', k=op[0].conv.kernel_size[0], m=op[0].conv.out_channels, conv1=op[0].conv, bn1=op[0].norm, act=op[0].active,
+                conv2=_conv_of(op[1])) for op in res_ops]
+    dws = [dict(kind='dw', k=1, kd=op[1].conv.kernel_size[0], m=op[0].conv.out_channels, conv1=op[0].conv, bn1=op[0].norm, act=op[0].active,
+                dconv=op[1].conv, bn2=op[1].norm, conv2=_conv_of(op[2])) for op in dw_ops]
+    return res, dws
+
+
+def _has_hooks(mods):
+    for m in mods:
+        for s in m.modules():
+            if s._forward_hooks or s._forward_pre_hooks or s._backward_hooks:
+                return True
+    return False
+
+
+def applicable(res_ops, dw_ops, x, training):
+    if not _ENABLED or not training or not x.is_cuda or ops.bn_sync() is not None or not ops.is_act(x):
+        return False
+    if len(res_ops) + len(dw_ops) == 0 or len(res_ops) + len(dw_ops) > L.TCONV_MAXSEG:
+        return False
+    n, c, h, w = x.shape
+    if not ops.tconv_applicable(n, h, w, 16, 3, 3, 1, 1):
+        return False
+    res, dws = _branches(res_ops, dw_ops)
+    for b in res + dws:
+        convs = [b['conv1'], b['conv2']] + ([b['dconv']] if b['kind'] == 'dw' else [])
+        if any('weight_orig' in cv._parameters or cv.stride[0] != 1 for cv in convs):      # spectral norm: general path
+            return False
+        norms = [b['bn1']] + ([b['bn2']] if b['kind'] == 'dw' else [])
+        if any(not isinstance(nm, cnn.BatchNorm2d) or not nm.training or not nm.track_running_stats or nm.momentum is None for nm in norms):
+            return False
+        if cnn._act_code(b['act'])[0] not in (L.ACT_RELU, L.ACT_LRELU):
+            return False
+        ks = [b['k'], b.get('kd', 1), b['conv2'].kernel_size[0]]
+        if any(k not in (1, 3, 5) for k in ks) or b['conv1'].padding[0] != (b['k'] - 1) // 2:
+            return False
+    if sum(_cs4(b['m']) for b in dws) > 4 * L.DWM_MAXQ:
+        return False
+    return not _has_hooks(list(res_ops) + list(dw_ops))
+
+
+class _Plan:
+    """Static layout of one unit: channel slices, persistent operand buffers and the preparation job table (cf. fused_block._Plan)."""
+
+    def __init__(self, res_ops, dw_ops, cin, cout, dev):
+        self.dev = dev
+        res, dws = _branches(res_ops, dw_ops)
+        self.mods = list(res_ops) + list(dw_ops)
+        for b in res + dws:
+            cnn._to_channels_last_(b['conv1'])
+            cnn._to_channels_last_(b['conv2'])
+        self.Cin, self.csi = cin, _cs4(cin)
+        self.Cout, self.cso = cout, _cs4(cout)
+        first = (res + dws)[0]
+        self.act, self.slope = cnn._act_code(first['act'])
+        self.eps, self.momentum = float(first['bn1'].eps), float(first['bn1'].momentum)
+        order = [b for b in res if b['k'] == 1] + dws + [b for b in res if b['k'] == 3] + [b for b in res if b['k'] == 5]
+        off = 0
+        for b in order:
+            b['o1'], b['w1'] = off, _cs4(b['m'])
+            off += b['w1']
+        self.hc1 = off
+        off = 0
+        for b in dws:
+            b['od'] = off
+            off += _cs4(b['m'])
+        self.hcd = off
+        self.dw_in0 = dws[0]['o1'] if dws else 0
+        self.branches, self.res, self.dws = order, res, dws
+        self.groups = []
+        for k in (1, 3, 5):
+            bs = [b for b in order if b['k'] == k]
+            if bs:
+                g0, g1 = bs[0]['o1'], bs[-1]['o1'] + bs[-1]['w1']
+                self.groups.append(dict(k=k, off=g0, width=g1 - g0, branches=bs))
+        z = lambda n: torch.zeros(max(n, 4), device=dev, dtype=torch.float32)
+        for g in self.groups:
+            g['pack'] = z(tconv.pack_floats(g['k'], self.csi, g['width']))
+        # non-affine norms (the depthwise branches' second norm of a SPADE block) read gamma = 1 / beta = 0 from the concatenated vectors
+        self.gamma1, self.beta1, self.bias1 = torch.ones(max(self.hc1, 4), device=dev), z(self.hc1), z(self.hc1)
+        self.gammad, self.betad, self.biasd = torch.ones(max(self.hcd, 4), device=dev), z(self.hcd), z(self.hcd)
+        self.bias2 = z(self.cso)
+        self.w25 = z(25 * max(self.hcd, 4))
+        self.has_bias1 = any(b['conv1'].bias is not None for b in order)
+        self.has_biasd = any(b['dconv'].bias is not None for b in dws)
+        self.has_bias2 = any(b['conv2'].bias is not None for b in order)
+        po = 0
+        for b in order:
+            k2 = b['k'] if b['kind'] == 'res' else 1
+            b['k2'], b['p2off'] = k2, po
+            po += tconv.pack_floats(k2, b['w1'], self.Cout)
+        self.pack2 = z(po)
+        po = 0
+        for b in order:
+            b['d2off'] = po
+            po += tconv.pack_floats(b['k2'], self.cso, b['m'])
+        self.dpack2 = z(po)
+        po = 0
+        for b in order:
+            b['d1off'] = po
+            po += tconv.pack_floats(b['k'], b['w1'], self.Cin)
+        self.dpack1 = z(po)
+        self.gv = dict(g1=z(self.hc1), b1=z(self.hc1), c1=z(self.hc1), gd=z(self.hcd), bd=z(self.hcd), cd=z(self.hcd), c2=z(self.cso))
+        self.targets = []       # (vector name, offset, n, parameter)
+        for b in order:
+            if b['bn1'].weight is not None:
+                self.targets += [('g1', b['o1'], b['m'], b['bn1'].weight), ('b1', b['o1'], b['m'], b['bn1'].bias)]
+            if b['conv1'].bias is not None:
+                self.targets.append(('c1', b['o1'], b['m'], b['conv1'].bias))
+            if b['conv2'].bias is not None:
+                self.targets.append(('c2', 0, self.Cout, b['conv2'].bias))
+        for b in dws:
+            if b['bn2'].weight is not None:
+                self.targets += [('gd', b['od'], b['m'], b['bn2'].weight), ('bd', b['od'], b['m'], b['bn2'].bias)]
+            if b['dconv'].bias is not None:
+                self.targets.append(('cd', b['od'], b['m'], b['dconv'].bias))
+        self.params = []
+        seen = set()
+        for m in self.mods:
+            for q in m.parameters():
+                if id(q) not in seen:
+                    seen.add(id(q))
+                    self.params.append(q)
+        self.scatter_jobs = None
+        self._build_jobs()
+        self.key = self.bkey = None
+
+    def _jobs_to_dev(self, jobs):
+        arr = (L.PrepJob * len(jobs))()
+        blk = 0
+        for i, j in enumerate(jobs):
+            for f, v in j.items():
+                if f == 'srcs':
+                    for k, pv in enumerate(v):
+                        arr[i].srcs[k] = pv
+                elif f != 'threads':
+                    setattr(arr[i], f, v)
+            nb = max(1, (j['threads'] + 255) // 256)
+            arr[i].block0, arr[i].nblocks = blk, nb
+            blk += nb
+        t = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.dev)
+        return t, len(jobs), blk
+
+    def _pack_job(self, w, dst_ptr, mode, nn, ck, ks, nt_total, col0):
+        wcl, wcs = ops.weight_cl(w)
+        if wcl.data_ptr() != w.data_ptr():
+            raise RuntimeError('fused SPADE unit: conv weights must be in kernel layout')
+        taps = ks * ks
+        c4 = _cs4(ck)
+        nfull, rem = c4 // 16, (c4 % 16) // 4
+        groups = nfull * taps + ((taps * rem + 3) // 4 if rem else 0)
+        ntw = (col0 + nn + 15) // 16 - col0 // 16
+        return dict(kind=0, srcs=[w.data_ptr()], dst=dst_ptr, mode=mode, Nn=nn, Ck=ck, ks=ks, wcs=wcs, wn=taps * wcs, c4=c4, nt_total=nt_total, col0=col0,
+                    threads=groups * ntw * 64)
+
+    def _build_jobs(self):
+        fwd, bwd = [], []
+        vec = lambda dst, off, srcs, n: dict(kind=1, srcs=[s.data_ptr() for s in srcs], nsrc=len(srcs), dst=dst.data_ptr() + 4 * off, n=n, threads=n)
+        for g in self.groups:
+            nt = (g['width'] + 15) // 16
+            for b in g['branches']:
+                fwd.append(self._pack_job(b['conv1'].weight, g['pack'].data_ptr(), tconv.FWD, b['m'], self.Cin, g['k'], nt, b['o1'] - g['off']))
+        nt2 = (self.Cout + 15) // 16
+        nt1 = (self.Cin + 15) // 16
+        for b in self.branches:
+            if b['bn1'].weight is not None:
+                fwd.append(vec(self.gamma1, b['o1'], [b['bn1'].weight], b['m']))
+                fwd.append(vec(self.beta1, b['o1'], [b['bn1'].bias], b['m']))
+            if b['conv1'].bias is not None:
+                fwd.append(vec(self.bias1, b['o1'], [b['conv1'].bias], b['m']))
+            fwd.append(self._pack_job(b['conv2'].weight, self.pack2.data_ptr() + 4 * b['p2off'], tconv.FWD, self.Cout, b['m'], b['k2'], nt2, 0))
+            bwd.append(self._pack_job(b['conv2'].weight, self.dpack2.data_ptr() + 4 * b['d2off'], tconv.DGRAD, b['m'], self.Cout, b['k2'], (b['m'] + 15) // 16, 0))
+            bwd.append(self._pack_job(b['conv1'].weight, self.dpack1.data_ptr() + 4 * b['d1off'], tconv.DGRAD, self.Cin, b['m'], b['k'], nt1, 0))
+        for b in self.dws:
+            if b['bn2'].weight is not None:
+                fwd.append(vec(self.gammad, b['od'], [b['bn2'].weight], b['m']))
+                fwd.append(vec(self.betad, b['od'], [b['bn2'].bias], b['m']))
+            if b['dconv'].bias is not None:
+                fwd.append(vec(self.biasd, b['od'], [b['dconv'].bias], b['m']))
+            kd = b['kd']
+            wd = b['dconv'].weight
+            if not wd.is_contiguous():
+                raise RuntimeError('fused SPADE unit: depthwise weights must be contiguous')
+            fwd.append(dict(kind=2, srcs=[wd.data_ptr()], dst=self.w25.data_ptr(), Nn=b['m'], ks=kd, col0=b['od'], cs=self.hcd, threads=b['m'] * kd * kd))
+        b2 = [b['conv2'].bias for b in self.branches if b['conv2'].bias is not None]
+        if b2:
+            fwd.append(vec(self.bias2, 0, b2, self.Cout))
+        self.ptrs = tuple(q.data_ptr() for q in self.params)
+        self.shapes = tuple(tuple(q.shape) for q in self.params)
+        self.ids = tuple(id(q) for q in self.params)
+        self.fwd_jobs = self._jobs_to_dev(fwd)
+        self.bwd_jobs = self._jobs_to_dev(bwd)
+
+    def _epoch_key(self):
+        trainable = any(getattr(q, '_cat_grad_view', None) is not None for q in self.params)
+        return (optim.weights_epoch() if trainable else -1, tuple(q._version for q in self.params))
+
+    def prepare(self, backward=False):
+        if tuple(q.data_ptr() for q in self.params) != self.ptrs:       # FusedAdam re-housed the parameters: same layout, new addresses
+            self._build_jobs()
+            self.key = self.bkey = self.scatter_jobs = None
+        key = self._epoch_key()
+        if backward:
+            if self.bkey != key:
+                t, n, blocks = self.bwd_jobs
+                L.call('cat_prep_run', ops._p(t), n, blocks, 0, ops._stream())
+                self.bkey = key
+        elif self.key != key:
+            t, n, blocks = self.fwd_jobs
+            L.call('cat_prep_run', ops._p(t), n, blocks, 0, ops._stream())
+            self.key = key
+
+
+def plan_for(owner, slot, res_ops, dw_ops, cin, cout, x):
+    p = getattr(owner, slot, None)
+    params = [q for m in list(res_ops) + list(dw_ops) for q in m.parameters()]
+    if p is None or p.dev != x.device or p.shapes != tuple(tuple(q.shape) for q in params) or p.ids != tuple(id(q) for q in params):
+        p = _Plan(res_ops, dw_ops, cin, cout, x.device)
+        setattr(owner, slot, p)
+    return p
+
+
+def _slices(pairs):
+    arr = (L.NSlice * len(pairs))()
+    for i, (c0, c, bn) in enumerate(pairs):
+        arr[i].c0, arr[i].c = c0, c
+        arr[i].running_mean = bn.running_mean.data_ptr()
+        arr[i].running_var = bn.running_var.data_ptr()
+        # SynchronizedBatchNorm2d.forward bypasses _BatchNorm.forward: num_batches_tracked is never advanced (batchnorm.py:68-101)
+        arr[i].num_batches = None if isinstance(bn, cnn.SynchronizedBatchNorm2d) else bn.num_batches_tracked.data_ptr()
+    return arr
+
+
+def _finalize(p, part, scs, n, h, w, gamma, beta, pairs):
+    ss = torch.empty((2, 1, scs), device=part.device, dtype=torch.float32)
+    mr = torch.empty((2, 1, scs), device=part.device, dtype=torch.float32)
+    L.call('cat_tnorm_finalize', ops._p(part), scs, 1, n, h, w, ops._p(gamma), ops._p(beta), len(pairs), _slices(pairs), p.eps, p.momentum,
+           ops._p(ss[0]), ops._p(ss[1]), ops._p(mr[0]), ops._p(mr[1]), scs, ops._stream())
+    return ss, mr
+
+
+def forward(p, x, addend, save=None):
+    """The unit's forward.  `addend`: NHWC activation [n, Cout, h, w] added in the epilogue (the block's shortcut) or None."""
+    p.prepare()
+    n, c, h, w = x.shape
+    dev = x.device
+    tiles = n * ((h + 7) // 8) * ((w + 15) // 16)
+    z1 = torch.empty((n, h, w, p.hc1), device=dev, dtype=torch.float32)
+    part1 = torch.empty((tiles, 2, p.hc1), device=dev, dtype=torch.float32)
+    by_k = {g['k']: g for g in p.groups}
+    if len(p.groups) == 3 and L.query('cat_tstage1_supported', by_k[5]['width'], by_k[3]['width'], by_k[1]['width']):
+        gs = L.Stage1Geom()
+        gs.N, gs.H, gs.W, gs.xcs, gs.cin, gs.reflect, gs.ycs, gs.scs = n, h, w, ops.act_cs(x), c, 0, p.hc1, p.hc1
+        packs = (C.c_void_p * 3)()
+        for slot, k in enumerate((5, 3, 1)):
+            g = by_k[k]
+            gs.col0[slot], gs.width[slot], gs.nvalid[slot] = g['off'], g['width'], sum(b['m'] for b in g['branches'])
+            packs[slot] = g['pack'].data_ptr()
+        L.call('cat_tstage1_fwd', C.byref(gs), ops._p(x), packs, ops._p(p.bias1) if p.has_bias1 else None, ops._p(z1), ops._p(part1), ops._stream())
+    else:
+        for g in p.groups:
+            pad = (g['k'] - 1) // 2
+            seg = tconv.Segment(x, g['k'], pad, False, 0)
+            tconv.run([seg], g['pack'], (p.bias1.data_ptr() + 4 * g['off']) if p.has_bias1 else None, None, g['width'], n, h, w, h, w, ycs=p.hc1,
+                      ycw=g['width'], yptr=z1.data_ptr() + 4 * g['off'], stats=part1.data_ptr() + 4 * g['off'], scs=p.hc1,
+                      nvalid=sum(b['m'] for b in g['branches']))
+    st1 = _finalize(p, part1, p.hc1, n, h, w, p.gamma1, p.beta1, [(b['o1'], b['m'], b['bn1']) for b in p.branches])
+    zd = std = None
+    if p.dws:
+        zd = torch.empty((n, h, w, p.hcd), device=dev, dtype=torch.float32)
+        partd = torch.empty((tiles, 2, p.hcd), device=dev, dtype=torch.float32)
+        gd = L.DwmGeom()
+        gd.N, gd.H, gd.W, gd.nq, gd.xcs, gd.ycs, gd.scs = n, h, w, p.hcd // 4, p.hc1, p.hcd, p.hcd
+        gd.sstride, gd.reflect, gd.act, gd.slope = 0, 0, p.act, p.slope
+        for b in p.dws:
+            for q in range(b['od'] // 4, (b['od'] + _cs4(b['m'])) // 4):
+                gd.ks[q] = b['kd']
+        o = p.dw_in0
+        L.call('cat_dwm_fwd', C.byref(gd), C.c_void_p(z1.data_ptr() + 4 * o), C.c_void_p(st1[0][0].data_ptr() + 4 * o),
+               C.c_void_p(st1[0][1].data_ptr() + 4 * o), ops._p(p.w25), ops._p(p.biasd) if p.has_biasd else None, ops._p(zd), ops._p(partd), ops._stream())
+        std = _finalize(p, partd, p.hcd, n, h, w, p.gammad, p.betad, [(b['od'], b['m'], b['bn2']) for b in p.dws])
+    segs = []
+    for b in p.branches:
+        if b['kind'] == 'res':
+            k = b['k']
+            segs.append(tconv.Segment(None, k, (k - 1) // 2, False, b['p2off'], c4=b['w1'], cin=b['m'], xcs=p.hc1, ptr=z1.data_ptr() + 4 * b['o1'],
+                                      scale=st1[0][0].data_ptr() + 4 * b['o1'], shift=st1[0][1].data_ptr() + 4 * b['o1'], act=p.act, slope=p.slope))
+        else:
+            segs.append(tconv.Segment(None, 1, 0, False, b['p2off'], c4=b['w1'], cin=b['m'], xcs=p.hcd, ptr=zd.data_ptr() + 4 * b['od'],
+                                      scale=std[0][0].data_ptr() + 4 * b['od'], shift=std[0][1].data_ptr() + 4 * b['od'], act=p.act, slope=p.slope))
+    y = ops.empty_act(n, p.Cout, h, w, dev)
+    tconv.run(segs, p.pack2, p.bias2 if p.has_bias2 else None, y, p.Cout, n, h, w, h, w, res=addend)
+    if save is not None:
+        save.update(z1=z1, zd=zd, st1=st1, std=std)
+    return y
+
+
+def _norm_bwd(p, n, hw, c, cs, x, dy, gamma, beta, mr, dgamma, dbeta):
+    g = L.NormGeom(n, hw, c, cs, L.NORM_BATCH, p.eps, p.momentum, p.act, p.slope)
+    dx = torch.empty((n, hw, cs), device=x.device, dtype=torch.float32)
+    ws = ops.workspace(L.query('cat_norm_ws_bytes', C.byref(g)), x.device)
+    L.call('cat_norm_bwd', C.byref(g), ops._p(x), ops._p(dy), ops._p(gamma), ops._p(beta), ops._p(mr[0]), ops._p(mr[1]), ops._p(dx), ops._p(dgamma),
+           ops._p(dbeta), 0, ops._p(ws), ops._stream())
+    return dx
+
+
+def _channel_sum(src, m_pix, c, cs, dst):
+    ws = ops.workspace(L.query('cat_channel_sum_ws_bytes', m_pix, cs), src.device)
+    L.call('cat_channel_sum', ops._p(src), m_pix, c, cs, ops._p(dst), 0, ops._p(ws), ops._stream())
+
+
+class _UnitFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, addend, plan, *params):
+        x = ops.conform(x)
+        if addend is not None:
+            addend = ops.conform(addend)
+        save = {}
+        y = forward(plan, x, addend, save)
+        ctx.plan = plan
+        ctx.has_dw = save['zd'] is not None
+        ctx.has_add = addend is not None
+        tensors = [x, save['z1'], save['st1'][0], save['st1'][1]]
+        if ctx.has_dw:
+            tensors += [save['zd'], save['std'][0], save['std'][1]]
+        ctx.save_for_backward(*tensors)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        p = ctx.plan
+        saved = ctx.saved_tensors
+        x, z1, ss1, mr1 = saved[:4]
+        zd, ssd, mrd = saved[4:] if ctx.has_dw else (None, None, None)
+        dt = ops.conform(dy)            # no closing norm: the gradient of the branch sum IS dy (and so is the addend's)
+        if ops.act_cs(dt) != p.cso:
+            raise RuntimeError('fused SPADE unit backward: gradient pixel stride differs from the activation')
+        p.prepare(backward=True)
+        n, c, h, w = x.shape
+        dev, hw, m_pix = x.device, h * w, n * h * w
+        st = ops._stream()
+        grads = {}
+        side = ops.SideJobs(dev)
+
+        def put_side(param, kernel):
+            def job():
+                grads[id(param)] = ops._write_param_grad(param, lambda dst_, acc: kernel(dst_, acc, ops._stream()))
+            side.run(job)
+
+        # ---- re-materialise the hidden activations (inputs of the second convs / of the depthwise convs)
+        a1 = torch.empty((n, h, w, p.hc1), device=dev, dtype=torch.float32)
+        L.call('cat_affine_res_fwd', ops._p(z1), p.hc1, ops._p(ss1[0]), ops._p(ss1[1]), 0, None, 0, ops._p(a1), p.hc1, 1, m_pix, p.hc1, p.act, p.slope, st)
+        da1 = torch.empty((n, h, w, p.hc1), device=dev, dtype=torch.float32)
+        ad = dad = None
+        if ctx.has_dw:
+            ad = torch.empty((n, h, w, p.hcd), device=dev, dtype=torch.float32)
+            L.call('cat_affine_res_fwd', ops._p(zd), p.hcd, ops._p(ssd[0]), ops._p(ssd[1]), 0, None, 0, ops._p(ad), p.hcd, 1, m_pix, p.hcd, p.act, p.slope, st)
+            dad = torch.empty((n, h, w, p.hcd), device=dev, dtype=torch.float32)
+        # ---- second convs: weight gradients from (hidden activation slice, dT); input gradients into slices of dA1 / dAd
+        side.fork()
+        for b in p.branches:
+            res = b['kind'] == 'res'
+            k2, m, w1 = b['k2'], b['m'], b['w1']
+            pad2 = (k2 - 1) // 2
+            src, scs_, o = (a1, p.hc1, b['o1']) if res else (ad, p.hcd, b['od'])
+            dst, dcs = (da1, p.hc1) if res else (dad, p.hcd)
+            xptr = C.c_void_p(src.data_ptr() + 4 * o)
+
+            def kw(dst_, acc, sst, xptr=xptr, m=m, scs_=scs_, k2=k2, pad2=pad2):
+                gw = ops._conv_geom(n, h, w, m, scs_, h, w, p.Cout, p.cso, k2, k2, 1, pad2, L.PAD_ZERO, wcs=ops._grad_wcs(dst_))
+                ws = ops.workspace(L.query('cat_conv2d_wgrad_ws_bytes', C.byref(gw)), dev)
+                L.call('cat_conv2d_wgrad', C.byref(gw), xptr, ops._p(dt), ops._p(dst_), acc, ops._p(ws), sst)
+            put_side(b['conv2'].weight, kw)
+            seg = tconv.Segment(None, k2, k2 - 1 - pad2, False, b['d2off'], c4=p.cso, cin=p.Cout, xcs=p.cso, ptr=dt.data_ptr())
+            tconv.run([seg], p.dpack2, None, None, m, n, h, w, h, w, ycs=dcs, ycw=w1, yptr=dst.data_ptr() + 4 * o)
+        if p.has_bias2:
+            _channel_sum(dt, m_pix, p.Cout, p.cso, p.gv['c2'])
+        # ---- depthwise stage
+        if ctx.has_dw:
+            dzd = _norm_bwd(p, n, hw, p.hcd, p.hcd, zd, dad, p.gammad, p.betad, mrd, p.gv['gd'], p.gv['bd'])
+            if p.has_biasd:
+                _channel_sum(dzd, m_pix, p.hcd, p.hcd, p.gv['cd'])
+            nb = len(p.dws)
+            gd = L.DwmGeom()
+            gd.N, gd.H, gd.W, gd.nq, gd.xcs, gd.ycs, gd.scs = n, h, w, p.hcd // 4, p.hc1, p.hcd, p.hcd
+            gd.reflect = 0
+            for b in p.dws:
+                for q in range(b['od'] // 4, (b['od'] + _cs4(b['m'])) // 4):
+                    gd.ks[q] = b['kd']
+            wts = [b['dconv'].weight for b in p.dws]
+            tg = [ops._grad_target(q) for q in wts]
+            if all(t_ is not None for t_ in tg):
+                fresh = {q._cat_grad_state['fresh'] for q in wts}
+                if len(fresh) != 1:
+                    raise RuntimeError('fused SPADE unit backward: depthwise gradient buffers out of sync')
+                acc_dw, dsts = (0 if fresh.pop() else 1), tg
+                for q in wts:
+                    q._cat_grad_state['fresh'] = False
+                    grads[id(q)] = None
+            else:
+                acc_dw, dsts = 0, [torch.empty_like(q) for q in wts]
+                for q, d_ in zip(wts, dsts):
+                    if ops._grad_target(q) is None:
+                        grads[id(q)] = d_
+            IA = C.c_int * nb
+            wsd = ops.workspace(L.query('cat_dwm_bwd_ws_bytes', C.byref(gd)), dev)
+            L.call('cat_dwm_bwd', C.byref(gd), C.c_void_p(a1.data_ptr() + 4 * p.dw_in0), ops._p(dzd), ops._p(p.w25),
+                   C.c_void_p(da1.data_ptr() + 4 * p.dw_in0), p.hc1, nb, IA(*[b['od'] for b in p.dws]), IA(*[b['m'] for b in p.dws]),
+                   IA(*[b['kd'] for b in p.dws]), (C.c_void_p * nb)(*[d_.data_ptr() for d_ in dsts]), acc_dw, ops._p(wsd), st)
+            if not all(t_ is not None for t_ in tg):
+                for q, d_ in zip(wts, dsts):
+                    tq = ops._grad_target(q)
+                    if tq is not None:
+                        (tq.copy_ if q._cat_grad_state['fresh'] else tq.add_)(d_)
+                        q._cat_grad_state['fresh'] = False
+                        grads[id(q)] = None
+        # ---- stage-1 norms (all branches at once)
+        dz1 = _norm_bwd(p, n, hw, p.hc1, p.hc1, z1, da1, p.gamma1, p.beta1, mr1, p.gv['g1'], p.gv['b1'])
+        if p.has_bias1:
+            _channel_sum(dz1, m_pix, p.hc1, p.hc1, p.gv['c1'])
+        # ---- first convs: weight gradients from (x, dZ1 slice)
+        side.refork()
+        for b in p.branches:
+            k, m = b['k'], b['m']
+            pad1 = (k - 1) // 2
+            dyp = C.c_void_p(dz1.data_ptr() + 4 * b['o1'])
+
+            def kw1(dst_, acc, sst, dyp=dyp, m=m, k=k, pad1=pad1):
+                gw = ops._conv_geom(n, h, w, c, ops.act_cs(x), h, w, m, p.hc1, k, k, 1, pad1, L.PAD_ZERO, wcs=ops._grad_wcs(dst_))
+                ws = ops.workspace(L.query('cat_conv2d_wgrad_ws_bytes', C.byref(gw)), dev)
+                L.call('cat_conv2d_wgrad', C.byref(gw), ops._p(x), dyp, ops._p(dst_), acc, ops._p(ws), sst)
+            put_side(b['conv1'].weight, kw1)
+        # ---- first convs: the input gradients as ONE K-concatenated launch
+        dx = None
+        if ctx.needs_input_grad[0]:
+            segs = []
+            for b in p.branches:
+                pad1 = (b['k'] - 1) // 2
+                segs.append(tconv.Segment(None, b['k'], pad1, False, b['d1off'], c4=b['w1'], cin=b['m'], xcs=p.hc1, ptr=dz1.data_ptr() + 4 * b['o1']))
+            dx = ops.empty_act(n, c, h, w, dev)
+            tconv.run(segs, p.dpack1, None, dx, c, n, h, w, h, w)
+        side.join()
+        # ---- scatter the concatenated parameter gradients
+        all_t = [q for _, _, _, q in p.targets]
+        owned = [getattr(q, '_cat_grad_view', None) is not None for q in all_t]
+        if all_t and all(owned):
+            fresh = {q._cat_grad_state['fresh'] for q in all_t}
+            if len(fresh) != 1:
+                raise RuntimeError('fused SPADE unit backward: gradient buffers of one unit out of sync')
+            views = tuple(q._cat_grad_view.data_ptr() for q in all_t)
+            if p.scatter_jobs is None or p.scatter_jobs[3] != views:
+                jobs = [dict(kind=3, srcs=[p.gv[v].data_ptr() + 4 * o, q._cat_grad_view.data_ptr()], nsrc=2, n=cnt, threads=cnt) for v, o, cnt, q in p.targets]
+                p.scatter_jobs = p._jobs_to_dev(jobs) + (views,)
+            tj, nj, nbk, _ = p.scatter_jobs
+            L.call('cat_prep_run', ops._p(tj), nj, nbk, 0 if fresh.pop() else 1, st)
+            for q in all_t:
+                q._cat_grad_state['fresh'] = False
+                grads[id(q)] = None
+        else:
+            for v, o, cnt, q in p.targets:
+                gq = p.gv[v][o:o + cnt].clone()
+                tgt = getattr(q, '_cat_grad_view', None)
+                if tgt is not None:
+                    stq = q._cat_grad_state
+                    (tgt.copy_ if stq['fresh'] else tgt.add_)(gq)
+                    stq['fresh'] = False
+                    gq = None
+                grads[id(q)] = gq
+        return (dx, dt if ctx.has_add else None, None) + tuple(grads.get(id(q)) for q in p.params)
+
+
+def apply(owner, slot, res_ops, dw_ops, cin, cout, x, addend=None):
+    """Run the unit `owner`'s branches (res_ops, dw_ops) on x through the fused path; `slot` names the attribute that caches its plan."""
+    p = plan_for(owner, slot, res_ops, dw_ops, cin, cout, ops.conform(x))
+    if not torch.is_grad_enabled():
+        return forward(p, ops.conform(x), None if addend is None else ops.conform(addend))
+    return _UnitFn.apply(x, addend, p, *p.params)

@@ -353,7 +353,12 @@ class InceptionSPADE(nn.Module):
         branch_ops = list(self.res_ops) + list(self.dw_ops)
         if not branch_ops:      # gamma = beta = 0: the plain param-free norm
             return pfn(x, fuse_act=fuse_act)
-        gb = _run_branches(branch_ops, seg)
+        from . import fused_spade
+        if fused_spade.applicable(self.res_ops, self.dw_ops, seg, self.training):
+            # all first convs / norms / depthwise convs / the 2C-channel branch sum of the gamma|beta net as 5 launches (cat_amd/fused_spade.py)
+            gb = fused_spade.apply(self, '_cat_fused_gb', self.res_ops, self.dw_ops, self.input_dim, 2 * self.output_dim, seg)
+        else:
+            gb = _run_branches(branch_ops, seg)
         if pfn.training or not pfn.track_running_stats:
             track = pfn.training and pfn.track_running_stats
             return ops.SpadeFn.apply(x, gb, pfn.running_mean if track else None, pfn.running_var if track else None, float(pfn.eps),
@@ -477,6 +482,10 @@ class SPADEInvertedResidualChannels(nn.Module):
         x_spade, x_short = ops.fanout(x, 2) if grad else (x, x)
         tmp = self.spade(x_spade, seg, fuse_act=self.active)
         tmp = self.active(tmp, applied=True)
+        from . import fused_spade
+        if fused_spade.applicable(self.res_ops, self.dw_ops, tmp, self.training):
+            return fused_spade.apply(self, '_cat_fused_main', self.res_ops, self.dw_ops, self.input_dim, self.output_dim, tmp,
+                                     addend=self._shortcut(x_short))
         return _run_branches(branch_ops, tmp, extra=(self._shortcut(x_short),))
 
     def remove_spectral_norm(self):

@@ -459,3 +459,75 @@ def test_spade_distill_step_mse_adaptors():
             moved = (ref - before).abs() > 0.5 * lr          # Adam's first step: +-lr per entry with a solid gradient
             agree = ((v.cpu() - before).sign() == (ref - before).sign())[moved].float().mean()
             assert float(agree) > 0.98, (i, k, float(agree))
+
+
+@pytest.mark.parametrize('fin,fout,channels', [(48, 24, None), (24, 24, None), (40, 16, [30, 6, 12])])
+def test_fused_spade_units_match_general_path(fin, fout, channels):
+    """cat_amd/fused_spade.py: the gamma|beta net of InceptionSPADE and the main six-branch unit of SPADEInvertedResidualChannels as 5
+    launches each (train-mode SyncBN on one rank, zero padding, C_in != C_out, learned / identity shortcut as the epilogue addend) against
+    the general per-layer path of the same module: output, input gradient, every parameter gradient, running statistics."""
+    import copy
+    from cat_amd import fused_spade, ops
+    from cat_amd.inception_modules import SPADEInvertedResidualChannels
+    g, opt, lab, ins, img, sds, cfg = fixture()
+    o = Namespace(**vars(opt))
+    o.norm_G, o.channels = 'spadesyncbatch3x3', channels
+    blk = SPADEInvertedResidualChannels(fin, fout, o)
+    blk.load_state_dict(detfill.fill_state_dict(blk.state_dict(), 411, gamma_abs_normal=True))
+    blk = blk.to(dev()).train()
+    ref = copy.deepcopy(blk)
+    n, h, w = 2, 24, 40
+    # (seed 600: no modulation pre-activation within round-off of the ReLU kink -- seeds 412 / 512 have one such unit of 76 800, which flips
+    # between the two paths and moves ONE element of dx by 1e-2 and the gamma|beta net's gradients by 1-3 %: tools/debug/fused_spade_dbg.py)
+    x = detfill.normal((n, fin, h, w), 600)
+    seg = (detfill.normal((n, o.semantic_nc, h // 4, w // 4), 413) > 0.8).float().repeat_interleave(4, 2).repeat_interleave(4, 3)
+    gy = detfill.normal((n, fout, h, w), 414)
+    old = ops.set_tconv_min_tiles(1)
+    try:
+        xa, sa = nhwc(x).detach().requires_grad_(True), nhwc(seg)
+        assert fused_spade.applicable(blk.res_ops, blk.dw_ops, xa, True)
+        # the unpruned gamma|beta net has 3 x 21 (-> 72) depthwise hidden channels: beyond the 64 the fused depthwise kernels hold -> general path
+        gb_fused = channels is not None
+        assert fused_spade.applicable(blk.spade.res_ops, blk.spade.dw_ops, sa, True) == gb_fused
+        ya = blk(xa, sa)
+        ya.backward(nhwc(gy))
+        assert getattr(blk, '_cat_fused_main', None) is not None and (getattr(blk.spade, '_cat_fused_gb', None) is not None) == gb_fused
+        fused_spade.set_enabled(False)
+        xb, sb = nhwc(x).detach().requires_grad_(True), nhwc(seg)
+        yb = ref(xb, sb)
+        yb.backward(nhwc(gy))
+    finally:
+        fused_spade.set_enabled(True)
+        ops.set_tconv_min_tiles(old)
+    torch.cuda.synchronize()
+    assert rel(ya, yb) < 2e-5, rel(ya, yb)
+    assert rel(xa.grad, xb.grad) < 1e-4, rel(xa.grad, xb.grad)
+    gtop = max(float(q.grad.abs().max()) for q in ref.parameters() if q.grad is not None)
+    from cat_amd.inception_modules import ConvSyncBNReLU
+    # a conv bias directly in front of a batch norm has exact gradient 0 (round-off in both paths)
+    zero_grad = {id(m.conv.bias) for m in ref.modules() if isinstance(m, ConvSyncBNReLU) and m.conv.bias is not None}
+    bad = {}
+    for (k, pa), (_, pb) in zip(blk.named_parameters(), ref.named_parameters()):
+        assert (pa.grad is None) == (pb.grad is None), k
+        if pb.grad is None or id(pb) in zero_grad:
+            continue
+        err = float((pa.grad - pb.grad).abs().max()) / max(float(pb.grad.abs().max()), 1e-3 * gtop)
+        if err > 1e-3:
+            bad[k] = err
+    assert not bad, bad
+    for (k, ba), (_, bb) in zip(blk.named_buffers(), ref.named_buffers()):
+        if ba.dtype.is_floating_point:
+            assert rel(ba, bb, 1e-6) < 1e-5, k
+        else:
+            assert torch.equal(ba, bb), k
+    # under no_grad (the D step's fake image) the fused forward equals the general one as well
+    with torch.no_grad():
+        old = ops.set_tconv_min_tiles(1)
+        try:
+            y1 = blk(nhwc(x), nhwc(seg))
+            fused_spade.set_enabled(False)
+            y2 = ref(nhwc(x), nhwc(seg))
+        finally:
+            fused_spade.set_enabled(True)
+            ops.set_tconv_min_tiles(old)
+    assert rel(y1, y2) < 2e-5
