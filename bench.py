@@ -412,6 +412,8 @@ def student_forward_rate(model, batch, spade, graph=True):
         torch.cuda.synchronize()
         ms_eager = e0.elapsed_time(e1) / reps
         if graph:
+            from cat_amd import parallel
+            parallel.settle_collectives()      # (--dp-schedule 1: collectives were issued in this process; see its docstring)
             g = torch.cuda.CUDAGraph()
             optim._bump_weights_epoch()
             with torch.cuda.graph(g):

@@ -11,6 +11,8 @@ torch.cuda.CUDAGraph, which also pins the caching-allocator pool the captured ke
 What is captured is exactly model.set_input + model.optimize_parameters, including the side-stream branches (fork / join
 events become graph dependencies) and both Adam updates.  Loss tensors are graph outputs: `model.get_current_losses()` reads
 them after a replay.  Data-parallel steps (RCCL collectives between the backward passes) stay eager."""
+import os
+
 import torch
 
 
@@ -124,6 +126,9 @@ class GraphedDPStep:
             model.finish_pending()
         cur.wait_stream(warm)
         torch.cuda.synchronize()
+        if self.dp:
+            from . import parallel
+            parallel.settle_collectives()      # the RCCL watchdog must not poll a warm-up collective's event inside a capture
         side = model._side_stream
         kw = dict(capture_error_mode='thread_local')      # RCCL's watchdog thread may query events while this thread captures
         self.g_in, self.g_T, self.g_A, self.g_B = (torch.cuda.CUDAGraph() for _ in range(4))

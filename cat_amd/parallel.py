@@ -75,6 +75,19 @@ def backend_version():
     return b
 
 
+def settle_collectives(seconds=None):
+    """Call before a hipGraph capture in a process that has issued RCCL collectives.  ProcessGroupNCCL's watchdog thread polls the events of
+    collectives it has not yet seen complete (every ~100 ms); a poll that lands inside a stream capture is refused by the HIP runtime
+    (hipErrorCapturedEvent: "operation not permitted on an event last recorded in a capturing stream") and the watchdog takes the process
+    down -- observed with a world_size-1 group when the capture started right after the warm-up steps.  After a device synchronize every
+    collective HAS completed; a few polling periods let the watchdog retire them."""
+    if not dist.is_initialized() or dist.get_backend() != 'nccl':
+        return
+    import time
+    torch.cuda.synchronize()
+    time.sleep(float(os.environ.get('CAT_DP_CAPTURE_SETTLE_S', '1.0')) if seconds is None else seconds)
+
+
 def shard_batch(batch, rank, world_size):
     """The chunk DataParallel.scatter would hand replica `rank` (contiguous split of dim 0, torch.chunk semantics)."""
     out = {}
