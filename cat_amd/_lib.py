@@ -37,7 +37,8 @@ class TConv(C.Structure):
                                                                                             ('seg', TSeg * TCONV_MAXSEG)]
 
 
-TNORM_MAXSLICE, DWM_MAXQ, PREP_MAXSRC = 8, 16, 8
+TNORM_MAXSLICE, DWM_MAXQ, PREP_MAXSRC = 8, 24, 8
+DWM_MAXQ_BWD = 16
 
 
 class NSlice(C.Structure):

@@ -164,6 +164,8 @@ struct DwmArgs {
   int ks[CAT_DWM_MAXQ];   // kernel size of each channel quad
 };
 
+// MAXQ = compile-time bound of p.nq (16: the training blocks; 24: frozen SPADE units with 3 x 21 -> 72 hidden channels)
+template <int MAXQ>
 __global__ __launch_bounds__(256) void dwm_fwd_kernel(DwmArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int TR = TH + 4, TC = TW + 4;
@@ -177,7 +179,7 @@ __global__ __launch_bounds__(256) void dwm_fwd_kernel(DwmArgs p) {
   const int g = p.sstride ? n : 0;       // per-image statistics (InstanceNorm) or one group
   for (int i = tid; i < 25 * p.nq; i += 256) *reinterpret_cast<f4*>(sw + i * 4) = *reinterpret_cast<const f4*>(p.w + i * 4);
   const float neg = p.act == CAT_ACT_RELU ? 0.f : (p.act == CAT_ACT_LRELU ? p.slope : 1.f);
-  constexpr int SIT = (TR * TC * CAT_DWM_MAXQ + 255) / 256;     // all of the thread's loads in flight before the first LDS store
+  constexpr int SIT = (TR * TC * MAXQ + 255) / 256;     // all of the thread's loads in flight before the first LDS store
   f4 xv[SIT];
   {
     const f4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -219,7 +221,7 @@ __global__ __launch_bounds__(256) void dwm_fwd_kernel(DwmArgs p) {
   const int py = px >> 4, pxx = px & 15;
   const bool pv = oy0 + py < p.H && ox0 + pxx < p.W;
   const int cnt = min(TH, p.H - oy0) * min(TW, p.W - ox0);
-  constexpr int MAXH = CAT_DWM_MAXQ / 2;
+  constexpr int MAXH = MAXQ / 2;
   f4 out[MAXH];
 #pragma unroll
   for (int k = 0; k < MAXH; ++k) {
@@ -331,13 +333,19 @@ int cat_dwm_fwd(const cat_dwm_t* g, const float* x, const float* scale, const fl
   }
   const int cs = g->nq * 4;
   const size_t lds = (size_t)((TH + 4) * (TW + 4) * cs + 25 * cs + 4 * cs) * sizeof(float);
-  CAT_REQUIRE(lds <= 96 * 1024, "dwm: %zu bytes of LDS (max 96 KB)", lds);
-  static cat::LdsOptIn optin;
-  cat::lds_optin(optin, (const void*)dwm_fwd_kernel, 96 * 1024);
+  CAT_REQUIRE(lds <= 112 * 1024, "dwm: %zu bytes of LDS (max 112 KB)", lds);
   double taps = 0.0;
   for (int q = 0; q < g->nq; ++q) taps += 4.0 * g->ks[q] * g->ks[q];
   cat::ProfScope prof("dwconv_fwd", 2.0 * (double)g->N * g->H * g->W * taps, 0.0, stream);
-  dwm_fwd_kernel<<<g->N * a.tiles, 256, lds, (hipStream_t)stream>>>(a);
+  if (g->nq <= 16) {
+    static cat::LdsOptIn optin;
+    cat::lds_optin(optin, (const void*)dwm_fwd_kernel<16>, 96 * 1024);
+    dwm_fwd_kernel<16><<<g->N * a.tiles, 256, lds, (hipStream_t)stream>>>(a);
+  } else {
+    static cat::LdsOptIn optin;
+    cat::lds_optin(optin, (const void*)dwm_fwd_kernel<CAT_DWM_MAXQ>, 112 * 1024);
+    dwm_fwd_kernel<CAT_DWM_MAXQ><<<g->N * a.tiles, 256, lds, (hipStream_t)stream>>>(a);
+  }
   return cat::check_launch("dwm_fwd");
 }
 
@@ -442,7 +450,7 @@ __global__ __launch_bounds__(256) void dwm_bwd_kernel(DwmBwdArgs p) {
   for (int i = tid; i < 25 * p.nq; i += 256) *reinterpret_cast<f4*>(sw + i * 4) = *reinterpret_cast<const f4*>(p.w + i * 4);
   // staging in two phases (all global loads of the thread in flight, then the LDS stores): one workgroup per CU (89 KB of LDS), so
   // nothing else would hide a load-store-load chain
-  constexpr int SIT = (TR * TC * CAT_DWM_MAXQ + 255) / 256;
+  constexpr int SIT = (TR * TC * CAT_DWM_MAXQ_BWD + 255) / 256;
   f4 zv[SIT], av[SIT];
 #pragma unroll
   for (int it = 0; it < SIT; ++it) {
@@ -564,7 +572,7 @@ size_t cat_dwm_bwd_ws_bytes(const cat_dwm_t* g) {
 
 int cat_dwm_bwd(const cat_dwm_t* g, const float* a, const float* dz, const float* w25, float* da, int dacs, int nbranch, const int* c0,
                 const int* c, const int* ks, float* const* dw, int accumulate, void* ws, cat_stream_t stream) {
-  CAT_REQUIRE(g->nq >= 1 && g->nq <= CAT_DWM_MAXQ && nbranch >= 1 && nbranch <= CAT_TNORM_MAXSLICE && ws, "dwm bwd: bad arguments");
+  CAT_REQUIRE(g->nq >= 1 && g->nq <= CAT_DWM_MAXQ_BWD && nbranch >= 1 && nbranch <= CAT_TNORM_MAXSLICE && ws, "dwm bwd: bad arguments");
   CAT_REQUIRE((g->xcs & 3) == 0 && (g->ycs & 3) == 0 && (dacs & 3) == 0 && g->xcs >= 4 * g->nq && g->ycs >= 4 * g->nq && dacs >= 4 * g->nq,
               "dwm bwd: channel layout");
   DwmBwdArgs p{};

@@ -76,7 +76,7 @@ def applicable(block, x):
     ks = [op[1][0].kernel_size[0] for op in block.res_ops] + [op[2][0].kernel_size[0] for op in block.dw_ops]
     if any(k not in (1, 3, 5) for k in ks):
         return False
-    if sum(_cs4(op[0][0].out_channels) for op in block.dw_ops) > 4 * L.DWM_MAXQ or len(block.res_ops) + len(block.dw_ops) > L.TCONV_MAXSEG:
+    if sum(_cs4(op[0][0].out_channels) for op in block.dw_ops) > 4 * L.DWM_MAXQ_BWD or len(block.res_ops) + len(block.dw_ops) > L.TCONV_MAXSEG:
         return False
     return not _has_hooks(block)
 

@@ -64,7 +64,13 @@ def _has_hooks(mods):
 
 
 def applicable(res_ops, dw_ops, x, training):
-    if not _ENABLED or not training or not x.is_cuda or ops.bn_sync() is not None or not ops.is_act(x):
+    """training: the train-mode path (batch statistics, autograd).  not training: the frozen path -- eval-mode norms under no_grad (the
+    teacher): the same three kernels with scale / shift folded from the running statistics, no statistics / finalize launches."""
+    if not _ENABLED or not x.is_cuda or not ops.is_act(x):
+        return False
+    if training and ops.bn_sync() is not None:
+        return False
+    if not training and torch.is_grad_enabled():
         return False
     if len(res_ops) + len(dw_ops) == 0 or len(res_ops) + len(dw_ops) > L.TCONV_MAXSEG:
         return False
@@ -77,14 +83,14 @@ def applicable(res_ops, dw_ops, x, training):
         if any('weight_orig' in cv._parameters or cv.stride[0] != 1 for cv in convs):      # spectral norm: general path
             return False
         norms = [b['bn1']] + ([b['bn2']] if b['kind'] == 'dw' else [])
-        if any(not isinstance(nm, cnn.BatchNorm2d) or not nm.training or not nm.track_running_stats or nm.momentum is None for nm in norms):
+        if any(not isinstance(nm, cnn.BatchNorm2d) or nm.training != training or not nm.track_running_stats or nm.momentum is None for nm in norms):
             return False
         if cnn._act_code(b['act'])[0] not in (L.ACT_RELU, L.ACT_LRELU):
             return False
         ks = [b['k'], b.get('kd', 1), b['conv2'].kernel_size[0]]
         if any(k not in (1, 3, 5) for k in ks) or b['conv1'].padding[0] != (b['k'] - 1) // 2:
             return False
-    if sum(_cs4(b['m']) for b in dws) > 4 * L.DWM_MAXQ:
+    if sum(_cs4(b['m']) for b in dws) > 4 * (L.DWM_MAXQ_BWD if training else L.DWM_MAXQ):
         return False
     return not _has_hooks(list(res_ops) + list(dw_ops))
 
@@ -345,6 +351,73 @@ def forward(p, x, addend, save=None):
     return y
 
 
+def _eval_affine(p):
+    """scale / shift of every norm from its running statistics (eval mode), concatenated like the train-mode finalize output; cached until
+    a tensor involved changes (the frozen teacher: once)."""
+    tensors = []
+    for b in p.branches:
+        tensors += [b['bn1'].weight, b['bn1'].bias, b['bn1'].running_mean, b['bn1'].running_var]
+    for b in p.dws:
+        tensors += [b['bn2'].weight, b['bn2'].bias, b['bn2'].running_mean, b['bn2'].running_var]
+    trainable = any(getattr(t, '_cat_grad_view', None) is not None for t in tensors if t is not None)
+    key = (tuple((t.data_ptr(), t._version) if t is not None else None for t in tensors), optim.weights_epoch() if trainable else -1)
+    cached = getattr(p, 'eval_ss', None)
+    if cached is not None and cached[0] == key:
+        return cached[1], cached[2]
+    dev = p.dev
+    ss1 = torch.zeros((2, max(p.hc1, 4)), device=dev, dtype=torch.float32)
+    ssd = torch.zeros((2, max(p.hcd, 4)), device=dev, dtype=torch.float32)
+    st = ops._stream()
+
+    def fold(bn, dst, off, m):
+        L.call('cat_bn_fold', ops._p(bn.weight), ops._p(bn.bias), ops._p(bn.running_mean), ops._p(bn.running_var), float(bn.eps), m,
+               C.c_void_p(dst[0].data_ptr() + 4 * off), C.c_void_p(dst[1].data_ptr() + 4 * off), st)
+    for b in p.branches:
+        fold(b['bn1'], ss1, b['o1'], b['m'])
+    for b in p.dws:
+        fold(b['bn2'], ssd, b['od'], b['m'])
+    p.eval_ss = (key, ss1, ssd)
+    return ss1, ssd
+
+
+def forward_eval(p, x, addend):
+    """The unit with eval-mode norms (no grad): stage 1 -> depthwise stage -> branch sum, the norms folded into the consumers' staging."""
+    p.prepare()
+    ss1, ssd = _eval_affine(p)
+    n, c, h, w = x.shape
+    dev = x.device
+    z1 = torch.empty((n, h, w, p.hc1), device=dev, dtype=torch.float32)
+    for g in p.groups:
+        pad = (g['k'] - 1) // 2
+        seg = tconv.Segment(x, g['k'], pad, False, 0)
+        tconv.run([seg], g['pack'], (p.bias1.data_ptr() + 4 * g['off']) if p.has_bias1 else None, None, g['width'], n, h, w, h, w, ycs=p.hc1,
+                  ycw=g['width'], yptr=z1.data_ptr() + 4 * g['off'], nvalid=sum(b['m'] for b in g['branches']))
+    zd = None
+    if p.dws:
+        zd = torch.empty((n, h, w, p.hcd), device=dev, dtype=torch.float32)
+        gd = L.DwmGeom()
+        gd.N, gd.H, gd.W, gd.nq, gd.xcs, gd.ycs, gd.scs = n, h, w, p.hcd // 4, p.hc1, p.hcd, p.hcd
+        gd.sstride, gd.reflect, gd.act, gd.slope = 0, 0, p.act, p.slope
+        for b in p.dws:
+            for q in range(b['od'] // 4, (b['od'] + _cs4(b['m'])) // 4):
+                gd.ks[q] = b['kd']
+        o = p.dw_in0
+        L.call('cat_dwm_fwd', C.byref(gd), C.c_void_p(z1.data_ptr() + 4 * o), C.c_void_p(ss1[0].data_ptr() + 4 * o), C.c_void_p(ss1[1].data_ptr() + 4 * o),
+               ops._p(p.w25), ops._p(p.biasd) if p.has_biasd else None, ops._p(zd), None, ops._stream())
+    segs = []
+    for b in p.branches:
+        if b['kind'] == 'res':
+            k = b['k']
+            segs.append(tconv.Segment(None, k, (k - 1) // 2, False, b['p2off'], c4=b['w1'], cin=b['m'], xcs=p.hc1, ptr=z1.data_ptr() + 4 * b['o1'],
+                                      scale=ss1[0].data_ptr() + 4 * b['o1'], shift=ss1[1].data_ptr() + 4 * b['o1'], act=p.act, slope=p.slope))
+        else:
+            segs.append(tconv.Segment(None, 1, 0, False, b['p2off'], c4=b['w1'], cin=b['m'], xcs=p.hcd, ptr=zd.data_ptr() + 4 * b['od'],
+                                      scale=ssd[0].data_ptr() + 4 * b['od'], shift=ssd[1].data_ptr() + 4 * b['od'], act=p.act, slope=p.slope))
+    y = ops.empty_act(n, p.Cout, h, w, dev)
+    tconv.run(segs, p.pack2, p.bias2 if p.has_bias2 else None, y, p.Cout, n, h, w, h, w, res=addend)
+    return y
+
+
 def _norm_bwd(p, n, hw, c, cs, x, dy, gamma, beta, mr, dgamma, dbeta):
     g = L.NormGeom(n, hw, c, cs, L.NORM_BATCH, p.eps, p.momentum, p.act, p.slope)
     dx = torch.empty((n, hw, cs), device=x.device, dtype=torch.float32)
@@ -523,5 +596,6 @@ def apply(owner, slot, res_ops, dw_ops, cin, cout, x, addend=None):
     """Run the unit `owner`'s branches (res_ops, dw_ops) on x through the fused path; `slot` names the attribute that caches its plan."""
     p = plan_for(owner, slot, res_ops, dw_ops, cin, cout, ops.conform(x))
     if not torch.is_grad_enabled():
-        return forward(p, ops.conform(x), None if addend is None else ops.conform(addend))
+        fn = forward if p.branches[0]['bn1'].training else forward_eval
+        return fn(p, ops.conform(x), None if addend is None else ops.conform(addend))
     return _UnitFn.apply(x, addend, p, *p.params)

@@ -330,7 +330,8 @@ int cat_affine_res_fwd(const float* x, int xcs, const float* scale, const float*
 /* All depthwise convs of a block (the groups=midp ConvBNReLU convs, inception_modules.py:166-173; k = 1 / 3 / 5 per channel quad) as one
  * launch over channel slices: input = first-stage pre-norm buffer with that stage's scale / shift + activation applied while staging,
  * output = concatenated pre-norm buffer + its per-tile statistics.  w25: [25][4*nq] filters embedded in a 5 x 5 frame (cat_prep_run). */
-#define CAT_DWM_MAXQ 16
+#define CAT_DWM_MAXQ 24      /* channel quads of the fused depthwise stage, forward (96 channels: 101 KB of LDS) */
+#define CAT_DWM_MAXQ_BWD 16  /* ... and of cat_dwm_bwd (two patches in LDS: 64 channels = 129 KB) */
 typedef struct {
   int N, H, W;
   int nq;               /* channel quads */

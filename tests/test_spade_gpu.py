@@ -531,3 +531,38 @@ def test_fused_spade_units_match_general_path(fin, fout, channels):
             fused_spade.set_enabled(True)
             ops.set_tconv_min_tiles(old)
     assert rel(y1, y2) < 2e-5
+
+
+@pytest.mark.parametrize('fin,fout', [(48, 24), (24, 24)])
+def test_fused_spade_units_frozen_match_general_path(fin, fout):
+    """The frozen (eval, no-grad) form of the fused SPADE units -- the teacher's blocks: running statistics folded into the consumers' staging,
+    3 launches per unit; the unpruned gamma|beta net (3 x 21 -> 72 depthwise hidden channels) included -- against the general path."""
+    import copy
+    from cat_amd import fused_spade, ops
+    from cat_amd.inception_modules import SPADEInvertedResidualChannels
+    g, opt, lab, ins, img, sds, cfg = fixture()
+    o = Namespace(**vars(opt))
+    o.norm_G, o.channels = 'spadesyncbatch3x3', None
+    blk = SPADEInvertedResidualChannels(fin, fout, o)
+    blk.load_state_dict(detfill.fill_state_dict(blk.state_dict(), 421, gamma_abs_normal=True))
+    blk = blk.to(dev()).eval()
+    n, h, w = 2, 24, 40
+    x = detfill.normal((n, fin, h, w), 422)
+    seg = (detfill.normal((n, o.semantic_nc, h // 4, w // 4), 423) > 0.8).float().repeat_interleave(4, 2).repeat_interleave(4, 3)
+    old = ops.set_tconv_min_tiles(1)
+    try:
+        with torch.no_grad():
+            xa, sa = nhwc(x), nhwc(seg)
+            assert fused_spade.applicable(blk.res_ops, blk.dw_ops, xa, False)
+            assert fused_spade.applicable(blk.spade.res_ops, blk.spade.dw_ops, sa, False)
+            y1 = blk(xa, sa)
+            assert getattr(blk, '_cat_fused_main', None) is not None and getattr(blk.spade, '_cat_fused_gb', None) is not None
+            fused_spade.set_enabled(False)
+            y2 = blk(nhwc(x), nhwc(seg))
+    finally:
+        fused_spade.set_enabled(True)
+        ops.set_tconv_min_tiles(old)
+    assert rel(y1, y2) < 2e-5, rel(y1, y2)
+    cs = ops.act_cs(y1)
+    full = torch.as_strided(y1, (n, cs, h, w), y1.stride())
+    assert cs == fout or float(full[:, fout:].abs().max()) == 0.0
