@@ -170,6 +170,21 @@ class _Plan:
                 self.targets += [('gd', b['od'], b['m'], b['bn2'].weight), ('bd', b['od'], b['m'], b['bn2'].bias)]
             if b['dconv'].bias is not None:
                 self.targets.append(('cd', b['od'], b['m'], b['dconv'].bias))
+        # merged weight-gradient launches (as in fused_block): the 1 x 1 first convs of all branches are ONE GEMM over the N-concatenated dZ1
+        # slice (x is read once instead of once per branch; rows of `w1` then go to the parameters), the 1 x 1 second convs of the depthwise
+        # branches one K-concatenated GEMM over the whole depthwise hidden buffer (columns of `w2`)
+        g1 = next((g for g in self.groups if g['k'] == 1), None)
+        self.merge1 = g1 if (g1 is not None and len(g1['branches']) > 1) else None
+        if self.merge1 is not None:
+            self.gv['w1'] = z(g1['width'] * self.csi)
+            for b in g1['branches']:
+                self.targets.append(('w1', (b['o1'] - g1['off']) * self.csi, b['m'] * self.csi, b['conv1'].weight))
+        self.merge2 = len(dws) > 1
+        self.targets2d = []      # (vector, src offset, rows, cols, src stride, parameter): dst stride = the parameter's own wcs
+        if self.merge2:
+            self.gv['w2'] = z(self.Cout * self.hcd)
+            for b in dws:
+                self.targets2d.append(('w2', b['od'], self.Cout, _cs4(b['m']), self.hcd, b['conv2'].weight))
         self.params = []
         seen = set()
         for m in self.mods:
@@ -493,9 +508,16 @@ class _UnitFn(torch.autograd.Function):
                 gw = ops._conv_geom(n, h, w, m, scs_, h, w, p.Cout, p.cso, k2, k2, 1, pad2, L.PAD_ZERO, wcs=ops._grad_wcs(dst_))
                 ws = ops.workspace(L.query('cat_conv2d_wgrad_ws_bytes', C.byref(gw)), dev)
                 L.call('cat_conv2d_wgrad', C.byref(gw), xptr, ops._p(dt), ops._p(dst_), acc, ops._p(ws), sst)
-            put_side(b['conv2'].weight, kw)
+            if res or not p.merge2:
+                put_side(b['conv2'].weight, kw)
             seg = tconv.Segment(None, k2, k2 - 1 - pad2, False, b['d2off'], c4=p.cso, cin=p.Cout, xcs=p.cso, ptr=dt.data_ptr())
             tconv.run([seg], p.dpack2, None, None, m, n, h, w, h, w, ycs=dcs, ycw=w1, yptr=dst.data_ptr() + 4 * o)
+        if p.merge2:
+            def kw2(sst):
+                gw = ops._conv_geom(n, h, w, p.hcd, p.hcd, h, w, p.Cout, p.cso, 1, 1, 1, 0, L.PAD_ZERO, wcs=p.hcd)
+                ws = ops.workspace(L.query('cat_conv2d_wgrad_ws_bytes', C.byref(gw)), dev)
+                L.call('cat_conv2d_wgrad', C.byref(gw), ops._p(ad), ops._p(dt), ops._p(p.gv['w2']), 0, ops._p(ws), sst)
+            side.run(lambda: kw2(ops._stream()))
         if p.has_bias2:
             _channel_sum(dt, m_pix, p.Cout, p.cso, p.gv['c2'])
         # ---- depthwise stage
@@ -543,7 +565,17 @@ class _UnitFn(torch.autograd.Function):
             _channel_sum(dz1, m_pix, p.hc1, p.hc1, p.gv['c1'])
         # ---- first convs: weight gradients from (x, dZ1 slice)
         side.refork()
+        if p.merge1 is not None:
+            g1 = p.merge1
+
+            def kw1m(sst):
+                gw = ops._conv_geom(n, h, w, c, ops.act_cs(x), h, w, g1['width'], p.hc1, 1, 1, 1, 0, L.PAD_ZERO, wcs=p.csi)
+                ws = ops.workspace(L.query('cat_conv2d_wgrad_ws_bytes', C.byref(gw)), dev)
+                L.call('cat_conv2d_wgrad', C.byref(gw), ops._p(x), C.c_void_p(dz1.data_ptr() + 4 * g1['off']), ops._p(p.gv['w1']), 0, ops._p(ws), sst)
+            side.run(lambda: kw1m(ops._stream()))
         for b in p.branches:
+            if p.merge1 is not None and b['k'] == 1:
+                continue
             k, m = b['k'], b['m']
             pad1 = (k - 1) // 2
             dyp = C.c_void_p(dz1.data_ptr() + 4 * b['o1'])
@@ -564,7 +596,7 @@ class _UnitFn(torch.autograd.Function):
             tconv.run(segs, p.dpack1, None, dx, c, n, h, w, h, w)
         side.join()
         # ---- scatter the concatenated parameter gradients
-        all_t = [q for _, _, _, q in p.targets]
+        all_t = [q for _, _, _, q in p.targets] + [t2[5] for t2 in p.targets2d]
         owned = [getattr(q, '_cat_grad_view', None) is not None for q in all_t]
         if all_t and all(owned):
             fresh = {q._cat_grad_state['fresh'] for q in all_t}
@@ -573,6 +605,8 @@ class _UnitFn(torch.autograd.Function):
             views = tuple(q._cat_grad_view.data_ptr() for q in all_t)
             if p.scatter_jobs is None or p.scatter_jobs[3] != views:
                 jobs = [dict(kind=3, srcs=[p.gv[v].data_ptr() + 4 * o, q._cat_grad_view.data_ptr()], nsrc=2, n=cnt, threads=cnt) for v, o, cnt, q in p.targets]
+                jobs += [dict(kind=4, srcs=[p.gv[v].data_ptr() + 4 * o, q._cat_grad_view.data_ptr()], nsrc=2, n=rows * cols, cs=cols, wn=sstr_,
+                              wcs=ops._grad_wcs(q._cat_grad_view), threads=rows * cols) for v, o, rows, cols, sstr_, q in p.targets2d]
                 p.scatter_jobs = p._jobs_to_dev(jobs) + (views,)
             tj, nj, nbk, _ = p.scatter_jobs
             L.call('cat_prep_run', ops._p(tj), nj, nbk, 0 if fresh.pop() else 1, st)
@@ -580,8 +614,7 @@ class _UnitFn(torch.autograd.Function):
                 q._cat_grad_state['fresh'] = False
                 grads[id(q)] = None
         else:
-            for v, o, cnt, q in p.targets:
-                gq = p.gv[v][o:o + cnt].clone()
+            def deliver(q, gq):
                 tgt = getattr(q, '_cat_grad_view', None)
                 if tgt is not None:
                     stq = q._cat_grad_state
@@ -589,6 +622,19 @@ class _UnitFn(torch.autograd.Function):
                     stq['fresh'] = False
                     gq = None
                 grads[id(q)] = gq
+            for v, o, cnt, q in p.targets:
+                flat = p.gv[v][o:o + cnt]
+                if q.dim() == 4:      # rows of the merged 1 x 1 weight gradient: back into the parameter's [O][1][1][wcs] storage
+                    gq = ops.padded_weight_like(q.shape, dev)
+                    torch.as_strided(gq, (cnt,), (1,), gq.storage_offset()).copy_(flat)
+                else:
+                    gq = flat.clone()
+                deliver(q, gq)
+            for v, o, rows, cols, sstr_, q in p.targets2d:
+                gq = ops.padded_weight_like(q.shape, dev)
+                src2 = torch.as_strided(p.gv[v], (rows, cols), (sstr_, 1), o)
+                torch.as_strided(gq, (rows, cols), (ops.weight_wcs(gq), 1), gq.storage_offset()).copy_(src2)
+                deliver(q, gq)
         return (dx, dt if ctx.has_add else None, None) + tuple(grads.get(id(q)) for q in p.params)
 
 
