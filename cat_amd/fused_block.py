@@ -601,8 +601,12 @@ class _BlockFn(torch.autograd.Function):
             views = tuple(q._cat_grad_view.data_ptr() for q in all_t)
             if p.scatter_jobs is None or p.scatter_jobs[3] != views:
                 jobs = [dict(kind=3, srcs=[p.gv[v].data_ptr() + 4 * o, q._cat_grad_view.data_ptr()], nsrc=2, n=cnt, threads=cnt) for v, o, cnt, q in p.targets]
-                jobs += [dict(kind=4, srcs=[p.gv[v].data_ptr() + 4 * o, q._cat_grad_view.data_ptr()], nsrc=2, n=rows * cols, cs=cols, wn=sstr_,
-                              wcs=ops._grad_wcs(q._cat_grad_view), threads=rows * cols) for v, o, rows, cols, sstr_, q in p.targets2d]
+                # a one-channel conv weight is stored unpadded (wcs 1): never more columns than the destination row holds
+                for v, o, rows, cols, sstr_, q in p.targets2d:
+                    wcs_q = ops._grad_wcs(q._cat_grad_view)
+                    cq = min(cols, wcs_q)
+                    jobs.append(dict(kind=4, srcs=[p.gv[v].data_ptr() + 4 * o, q._cat_grad_view.data_ptr()], nsrc=2, n=rows * cq, cs=cq, wn=sstr_,
+                                     wcs=wcs_q, threads=rows * cq))
                 p.scatter_jobs = p._jobs_to_dev(jobs) + (views,)
             tj, nj, nb, _ = p.scatter_jobs
             L.call('cat_prep_run', ops._p(tj), nj, nb, 0 if fresh.pop() else 1, st)
@@ -628,6 +632,7 @@ class _BlockFn(torch.autograd.Function):
                 deliver(q, gq)
             for v, o, rows, cols, sstr_, q in p.targets2d:
                 gq = ops.padded_weight_like(q.shape, dev)
+                cols = min(cols, ops.weight_wcs(gq))
                 src2 = torch.as_strided(p.gv[v], (rows, cols), (sstr_, 1), o)
                 torch.as_strided(gq, (rows, cols), (ops.weight_wcs(gq), 1), gq.storage_offset()).copy_(src2)
                 deliver(q, gq)

@@ -30,7 +30,12 @@ from . import ops
 from . import optim
 from . import tconv
 
-_ENABLED = os.environ.get('CAT_FUSED_SPADE', '1') != '0'
+_ENABLED = os.environ.get('CAT_FUSED_SPADE', '1') != '0'      # A/B switch; 'train' / 'frozen' select one of the two forms
+_ONLY = os.environ.get('CAT_FUSED_SPADE', '1') if os.environ.get('CAT_FUSED_SPADE', '1') in ('train', 'frozen') else None
+
+
+_UNITS = os.environ.get('CAT_FUSED_SPADE_UNITS', 'all')      # A/B switch: 'gb' / 'main' = only the gamma|beta nets / only the main units
+STATS = {'train_fwd': 0, 'frozen_fwd': 0, 'bwd': 0}      # calls per form (tests / diagnostics)
 
 
 def set_enabled(on):
@@ -67,6 +72,8 @@ def applicable(res_ops, dw_ops, x, training):
     """training: the train-mode path (batch statistics, autograd).  not training: the frozen path -- eval-mode norms under no_grad (the
     teacher): the same three kernels with scale / shift folded from the running statistics, no statistics / finalize launches."""
     if not _ENABLED or not x.is_cuda or not ops.is_act(x):
+        return False
+    if _ONLY is not None and _ONLY != ('train' if training else 'frozen'):
         return False
     if training and ops.bn_sync() is not None:
         return False
@@ -312,6 +319,7 @@ def _finalize(p, part, scs, n, h, w, gamma, beta, pairs):
 
 def forward(p, x, addend, save=None):
     """The unit's forward.  `addend`: NHWC activation [n, Cout, h, w] added in the epilogue (the block's shortcut) or None."""
+    STATS['train_fwd'] += 1
     p.prepare()
     n, c, h, w = x.shape
     dev = x.device
@@ -397,6 +405,7 @@ def _eval_affine(p):
 
 def forward_eval(p, x, addend):
     """The unit with eval-mode norms (no grad): stage 1 -> depthwise stage -> branch sum, the norms folded into the consumers' staging."""
+    STATS['frozen_fwd'] += 1
     p.prepare()
     ss1, ssd = _eval_affine(p)
     n, c, h, w = x.shape
@@ -467,6 +476,7 @@ class _UnitFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         p = ctx.plan
+        STATS['bwd'] += 1
         saved = ctx.saved_tensors
         x, z1, ss1, mr1 = saved[:4]
         zd, ssd, mrd = saved[4:] if ctx.has_dw else (None, None, None)
@@ -605,8 +615,12 @@ class _UnitFn(torch.autograd.Function):
             views = tuple(q._cat_grad_view.data_ptr() for q in all_t)
             if p.scatter_jobs is None or p.scatter_jobs[3] != views:
                 jobs = [dict(kind=3, srcs=[p.gv[v].data_ptr() + 4 * o, q._cat_grad_view.data_ptr()], nsrc=2, n=cnt, threads=cnt) for v, o, cnt, q in p.targets]
-                jobs += [dict(kind=4, srcs=[p.gv[v].data_ptr() + 4 * o, q._cat_grad_view.data_ptr()], nsrc=2, n=rows * cols, cs=cols, wn=sstr_,
-                              wcs=ops._grad_wcs(q._cat_grad_view), threads=rows * cols) for v, o, rows, cols, sstr_, q in p.targets2d]
+                # a one-channel conv weight is stored unpadded (wcs 1): never more columns than the destination row holds
+                for v, o, rows, cols, sstr_, q in p.targets2d:
+                    wcs_q = ops._grad_wcs(q._cat_grad_view)
+                    cq = min(cols, wcs_q)
+                    jobs.append(dict(kind=4, srcs=[p.gv[v].data_ptr() + 4 * o, q._cat_grad_view.data_ptr()], nsrc=2, n=rows * cq, cs=cq, wn=sstr_,
+                                     wcs=wcs_q, threads=rows * cq))
                 p.scatter_jobs = p._jobs_to_dev(jobs) + (views,)
             tj, nj, nbk, _ = p.scatter_jobs
             L.call('cat_prep_run', ops._p(tj), nj, nbk, 0 if fresh.pop() else 1, st)
@@ -632,6 +646,7 @@ class _UnitFn(torch.autograd.Function):
                 deliver(q, gq)
             for v, o, rows, cols, sstr_, q in p.targets2d:
                 gq = ops.padded_weight_like(q.shape, dev)
+                cols = min(cols, ops.weight_wcs(gq))
                 src2 = torch.as_strided(p.gv[v], (rows, cols), (sstr_, 1), o)
                 torch.as_strided(gq, (rows, cols), (ops.weight_wcs(gq), 1), gq.storage_offset()).copy_(src2)
                 deliver(q, gq)

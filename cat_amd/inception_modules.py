@@ -354,7 +354,7 @@ class InceptionSPADE(nn.Module):
         if not branch_ops:      # gamma = beta = 0: the plain param-free norm
             return pfn(x, fuse_act=fuse_act)
         from . import fused_spade
-        if fused_spade.applicable(self.res_ops, self.dw_ops, seg, self.training):
+        if fused_spade._UNITS in ('all', 'gb') and fused_spade.applicable(self.res_ops, self.dw_ops, seg, self.training):
             # all first convs / norms / depthwise convs / the 2C-channel branch sum of the gamma|beta net as 5 launches (cat_amd/fused_spade.py)
             gb = fused_spade.apply(self, '_cat_fused_gb', self.res_ops, self.dw_ops, self.input_dim, 2 * self.output_dim, seg)
         else:
@@ -483,7 +483,7 @@ class SPADEInvertedResidualChannels(nn.Module):
         tmp = self.spade(x_spade, seg, fuse_act=self.active)
         tmp = self.active(tmp, applied=True)
         from . import fused_spade
-        if fused_spade.applicable(self.res_ops, self.dw_ops, tmp, self.training):
+        if fused_spade._UNITS in ('all', 'main') and fused_spade.applicable(self.res_ops, self.dw_ops, tmp, self.training):
             return fused_spade.apply(self, '_cat_fused_main', self.res_ops, self.dw_ops, self.input_dim, self.output_dim, tmp,
                                      addend=self._shortcut(x_short))
         return _run_branches(branch_ops, tmp, extra=(self._shortcut(x_short),))

@@ -130,6 +130,38 @@ def test_fused_block_backward_matches_torch(norm, padding, shape):
     assert not bad, bad
 
 
+def test_fused_block_backward_into_optimizer_buffers_with_one_channel_branches():
+    """As in the training step the gradients are slices of FusedAdam's flat buffer, where a conv weight with ONE input channel is stored
+    unpadded ([O][1][1][1]); depthwise branches pruned to a single channel are scattered there from the K-concatenated weight gradient
+    without touching the neighbouring parameters (every gradient against stock PyTorch autograd on the host)."""
+    from cat_amd import _lib, fused_block, ops
+    from cat_amd.optim import FusedAdam
+    _lib.load()
+    dev = torch.device('cuda:0')
+    n, c, h, w = 8, 40, 32, 48
+    blk = _block('batch', dev, c, (1, 0, 9), (1, 5, 1), 'reflect')
+    twin, twin_fwd = _torch_twin(blk)
+    FusedAdam(list(blk.parameters()), lr=0.0).zero_grad()
+    x, gy = detfill.normal((n, c, h, w), 5), detfill.normal((n, c, h, w), 6)
+    xr = x.clone().requires_grad_(True)
+    twin_fwd(xr).backward(gy)
+    xg = ops.to_nhwc(x.to(dev)).detach().requires_grad_(True)
+    assert fused_block.applicable(blk, xg)
+    blk(xg).backward(ops.to_nhwc(gy.to(dev)))
+    torch.cuda.synchronize()
+    assert rel(xg.grad, xr.grad) < 2e-4, rel(xg.grad, xr.grad)
+    tgrads = dict(twin.named_parameters())
+    top = max(float(q.grad.abs().max()) for q in tgrads.values())
+    bad = {}
+    for k, q in blk.named_parameters():
+        ref = tgrads[k].grad
+        assert q.grad is not None and q.grad.data_ptr() == q._cat_grad_view.data_ptr(), k
+        err = float((q.grad.detach().cpu() - ref).abs().max()) / max(float(ref.abs().max()), 1e-3 * top)
+        if err > 5e-4:
+            bad[k] = err
+    assert not bad, bad
+
+
 def test_fused_block_plan_follows_replaced_parameters():
     """A parameter object replaced by a new one of the same shape (weight transfer, `m.weight = nn.Parameter(...)`) must receive its
     gradient: the cached plan keys gradient targets by parameter identity and is rebuilt when the identities change."""

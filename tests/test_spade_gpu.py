@@ -461,8 +461,9 @@ def test_spade_distill_step_mse_adaptors():
             assert float(agree) > 0.98, (i, k, float(agree))
 
 
-@pytest.mark.parametrize('fin,fout,channels', [(48, 24, None), (24, 24, None), (40, 16, [30, 6, 12])])
-def test_fused_spade_units_match_general_path(fin, fout, channels):
+@pytest.mark.parametrize('fin,fout,channels,owned', [(48, 24, None, False), (24, 24, None, False), (40, 16, [30, 6, 12], False),
+                                                     (40, 16, [30, 6, 12], True), (24, 24, [6, 6, 6], True)])
+def test_fused_spade_units_match_general_path(fin, fout, channels, owned):
     """cat_amd/fused_spade.py: the gamma|beta net of InceptionSPADE and the main six-branch unit of SPADEInvertedResidualChannels as 5
     launches each (train-mode SyncBN on one rank, zero padding, C_in != C_out, learned / identity shortcut as the epilogue addend) against
     the general per-layer path of the same module: output, input gradient, every parameter gradient, running statistics."""
@@ -476,6 +477,12 @@ def test_fused_spade_units_match_general_path(fin, fout, channels):
     blk.load_state_dict(detfill.fill_state_dict(blk.state_dict(), 411, gamma_abs_normal=True))
     blk = blk.to(dev()).train()
     ref = copy.deepcopy(blk)
+    if owned:
+        # as in the training step: parameters and gradients are slices of FusedAdam's flat buffers, where a one-channel conv weight is
+        # stored unpadded (the concatenated gradients are scattered there by one launch: no write may leave its parameter's span)
+        from cat_amd.optim import FusedAdam
+        for net in (blk, ref):
+            FusedAdam(list(net.parameters()), lr=0.0).zero_grad()
     n, h, w = 2, 24, 40
     # (seed 600: no modulation pre-activation within round-off of the ReLU kink -- seeds 412 / 512 have one such unit of 76 800, which flips
     # between the two paths and moves ONE element of dx by 1e-2 and the gamma|beta net's gradients by 1-3 %: tools/debug/fused_spade_dbg.py)

@@ -1,12 +1,12 @@
 set -x
 export TMPDIR=/tmp
-O=gpurun_out/r3final; mkdir -p $O
+O=$PWD/gpurun_out/r3final; mkdir -p $O
 ( time timeout 1500 python -m pytest tests -m gpu -x -q -p no:cacheprovider ) > $O/pytest.log 2>&1; echo "pytest rc $?" >> $O/pytest.log
 tail -6 $O/pytest.log
 python -c 'import __graft_entry__ as g; g.smoke()' > $O/smoke.log 2>&1; tail -1 $O/smoke.log
 python bench.py --workload spade > $O/bench_spade.json 2> $O/bench_spade.err
 export CAT_BRANCH_STREAMS=0
-(cd /tmp && rocprofv3 --kernel-trace --stats -d $O/prof_spade -o bench -- python /root/repo/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-profile --graph 0 --sustained-steps 0 --workload spade > $O/prof_spade.log 2>&1)
+(cd /tmp && rocprofv3 --kernel-trace --stats -d $O/prof_spade -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-profile --graph 0 --sustained-steps 0 --workload spade > $O/prof_spade.log 2>&1)
 python tools/rocprof_summary.py $O/prof_spade/bench_results.db $O/kernel_stats_spade.txt 6 > /dev/null
 rm -rf $O/prof_spade
 python - <<P
