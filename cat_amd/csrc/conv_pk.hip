@@ -658,9 +658,13 @@ int cat_tconv_fwd(const cat_tconv_t* g, const float* pack, const float* bias, fl
   L.nblk = cat::cdiv(L.nt_total, 8);
   const int nt = cat::cdiv(L.nt_total, L.nblk);
   L.nblk = cat::cdiv(L.nt_total, nt);
-  // 8 x 16 pixel tiles unless that makes a very large grid (then 8 x 32: half the halo traffic, twice the filter reuse per wave)
+  // 8 x 16 pixel tiles; 8 x 32 (half the halo traffic, twice the filter reuse per wave) only for a very large grid of ONE N tile: with
+  // more N tiles the 4 x NT accumulator tiles cost occupancy (tconv_kernel<4, 32>: 231 registers, 2 waves / SIMD; <5..8, 32>: 257..337,
+  // 1 wave / SIMD) -- measured on the GauGAN step (round 3): 8 x 32 for every NT 62.8-63.0, NT <= 2 64.3, NT == 1 64.0-66.9, never 63.6 images/s
   const int64_t wg16 = (int64_t)g->N * cat::cdiv(g->Ho, 8) * cat::cdiv(g->Wo, 16) * L.nblk;
-  const int tw = g->stats ? 16 : (tw_env ? tw_env : (wg16 >= 4096 ? 32 : 16));
+  static const int tw32_maxnt = getenv("CAT_PK_TW32_MAXNT") ? atoi(getenv("CAT_PK_TW32_MAXNT")) : 1;
+  static const int tw32_minwg = getenv("CAT_PK_TW32_MINWG") ? atoi(getenv("CAT_PK_TW32_MINWG")) : 4096;
+  const int tw = g->stats ? 16 : (tw_env ? tw_env : (wg16 >= tw32_minwg && nt <= tw32_maxnt ? 32 : 16));
   CAT_REQUIRE(tw == 16 || tw == 32, "tconv: CAT_PK_TW must be 16 or 32");
   CAT_REQUIRE(g->stats == nullptr || (g->act == CAT_ACT_NONE && g->res == nullptr && g->scs >= g->ycw), "tconv: statistics need a plain epilogue");
   L.ablate = getenv("CAT_PK_ABLATE") ? atoi(getenv("CAT_PK_ABLATE")) : 0;
