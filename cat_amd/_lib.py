@@ -84,6 +84,8 @@ SIGNATURES = {
     'cat_tconv_fwd': (c_i, [_TG, c_p, c_p, c_p, c_p]),
     'cat_tstage1_supported': (c_i, [c_i, c_i, c_i]),
     'cat_tstage1_fwd': (c_i, [C.POINTER(Stage1Geom), c_p, c_p, c_p, c_p, c_p, c_p]),
+    'cat_tstage1_dgrad_supported': (c_i, [c_i, c_i, c_i]),
+    'cat_tstage1_dgrad': (c_i, [C.POINTER(Stage1Geom), c_p, c_p, c_p, c_p, c_p]),
     'cat_tnorm_finalize': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_i, c_p]),
     'cat_reflect_pad_bwd2': (c_i, [c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     'cat_affine_res_fwd': (c_i, [c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_p]),

@@ -366,13 +366,13 @@ __global__ __launch_bounds__(256) void tconv_kernel(const cat_tconv_t g, const f
 // tiles), three filter streams, outputs = three channel slices of the pre-norm buffer + their per-tile statistics.  The narrow convs
 // alone cannot hide their own staging latency (a 3x3 chunk is ~1 us of MFMA work); together a chunk carries ~7 us.
 struct S1Args {
-  const float* x; const float* pack[3]; const float* bias; float* y; float* stats;
-  int xcs, c4, N, H, W, reflect, ycs, scs;
+  const float* x; const float* pack[3]; const float* bias; float* ys[3]; float* stats;   // ys / ycs3: output buffer and pixel stride per slot
+  int xcs, c4, N, H, W, reflect, ycs3[3], scs;
   int nt_total[3], col0[3], width[3], nvalid[3];
   int hl, tr, tc, tiles_x, tiles;
 };
 
-template <int NT>
+template <int NT, bool STATS>
 __device__ __forceinline__ void s1_epilogue(f4 (&acc)[2][NT], const S1Args& p, int k, int n, int tt, int oy0, int ox0, int wave, int lr, int lq,
                                             float* red) {
   const int col0 = p.col0[k], width = p.width[k], nv = width;   // padding columns inside the slice carry zero filters: plain zeros come out
@@ -382,55 +382,60 @@ __device__ __forceinline__ void s1_epilogue(f4 (&acc)[2][NT], const S1Args& p, i
   for (int j = 0; j < NT; ++j) {
     const int co = j * 16 + lr;
     bv[j] = (p.bias && co < nv) ? p.bias[col0 + co] : 0.f;
-    float a = 0.f;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const bool rowv = oy0 + 2 * wave + i < p.H;
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) a += (rowv && ox0 + lq * 4 + rg < p.W) ? acc[i][j][rg] + bv[j] : 0.f;
-    }
-    a += __shfl_xor(a, 16, 64);
-    a += __shfl_xor(a, 32, 64);
-    if (lq == 0) red[wave * NT * 16 + j * 16 + lr] = a;
   }
-  __syncthreads();
+  if constexpr (STATS) {     // per-tile statistics; the input-gradient use of the kernel has none
 #pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int c = j * 16 + lr;
-    s[j] = (red[c] + red[NT * 16 + c]) + (red[2 * NT * 16 + c] + red[3 * NT * 16 + c]);
-    mean[j] = s[j] / (float)cnt;
-  }
-  float* red2 = red + 4 * NT * 16;
+    for (int j = 0; j < NT; ++j) {
+      float a = 0.f;
 #pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    float a = 0.f;
+      for (int i = 0; i < 2; ++i) {
+        const bool rowv = oy0 + 2 * wave + i < p.H;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const bool rowv = oy0 + 2 * wave + i < p.H;
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        const float d = acc[i][j][rg] + bv[j] - mean[j];
-        a += (rowv && ox0 + lq * 4 + rg < p.W) ? d * d : 0.f;
+        for (int rg = 0; rg < 4; ++rg) a += (rowv && ox0 + lq * 4 + rg < p.W) ? acc[i][j][rg] + bv[j] : 0.f;
       }
+      a += __shfl_xor(a, 16, 64);
+      a += __shfl_xor(a, 32, 64);
+      if (lq == 0) red[wave * NT * 16 + j * 16 + lr] = a;
     }
-    a += __shfl_xor(a, 16, 64);
-    a += __shfl_xor(a, 32, 64);
-    if (lq == 0) red2[wave * NT * 16 + j * 16 + lr] = a;
-  }
-  __syncthreads();
-  if (wave == 0 && lq == 0) {
-    float* dst = p.stats + (int64_t)tt * 2 * p.scs + col0;
+    __syncthreads();
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int c = j * 16 + lr;
-      if (c < width) {
-        const bool cv = c < nv;
-        dst[c] = cv ? s[j] : 0.f;
-        dst[p.scs + c] = cv ? (red2[c] + red2[NT * 16 + c]) + (red2[2 * NT * 16 + c] + red2[3 * NT * 16 + c]) : 0.f;
+      s[j] = (red[c] + red[NT * 16 + c]) + (red[2 * NT * 16 + c] + red[3 * NT * 16 + c]);
+      mean[j] = s[j] / (float)cnt;
+    }
+    float* red2 = red + 4 * NT * 16;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      float a = 0.f;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const bool rowv = oy0 + 2 * wave + i < p.H;
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const float d = acc[i][j][rg] + bv[j] - mean[j];
+          a += (rowv && ox0 + lq * 4 + rg < p.W) ? d * d : 0.f;
+        }
+      }
+      a += __shfl_xor(a, 16, 64);
+      a += __shfl_xor(a, 32, 64);
+      if (lq == 0) red2[wave * NT * 16 + j * 16 + lr] = a;
+    }
+    __syncthreads();
+    if (wave == 0 && lq == 0) {
+      float* dst = p.stats + (int64_t)tt * 2 * p.scs + col0;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int c = j * 16 + lr;
+        if (c < width) {
+          const bool cv = c < nv;
+          dst[c] = cv ? s[j] : 0.f;
+          dst[p.scs + c] = cv ? (red2[c] + red2[NT * 16 + c]) + (red2[2 * NT * 16 + c] + red2[3 * NT * 16 + c]) : 0.f;
+        }
       }
     }
+    __syncthreads();   // red is reused by the next sub-convolution
   }
-  __syncthreads();   // red is reused by the next sub-convolution
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int oy = oy0 + 2 * wave + i;
@@ -439,7 +444,7 @@ __device__ __forceinline__ void s1_epilogue(f4 (&acc)[2][NT], const S1Args& p, i
     for (int rg = 0; rg < 4; ++rg) {
       const int ox = ox0 + lq * 4 + rg;
       if (ox >= p.W) continue;
-      float* yo = p.y + (((int64_t)n * p.H + oy) * p.W + ox) * p.ycs + col0;
+      float* yo = p.ys[k] + (((int64_t)n * p.H + oy) * p.W + ox) * p.ycs3[k] + col0;
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const int co = j * 16 + lr;
@@ -450,7 +455,7 @@ __device__ __forceinline__ void s1_epilogue(f4 (&acc)[2][NT], const S1Args& p, i
   }
 }
 
-template <int NA, int NB, int NC>
+template <int NA, int NB, int NC, bool STATS>
 __global__ __launch_bounds__(256) void tstage1_kernel(const S1Args p) {
   constexpr int MT = 2, TW = 16, MAXIT = ((TH + 4) * (TW + 4) * 4 + 255) / 256;
   constexpr int NMAX = NA > NB ? (NA > NC ? NA : NC) : (NB > NC ? NB : NC);
@@ -565,9 +570,9 @@ __global__ __launch_bounds__(256) void tstage1_kernel(const S1Args p) {
     }
   }
   __syncthreads();
-  if constexpr (NA > 0) s1_epilogue<NA>(accA, p, 0, n, tt, oy0, ox0, wave, lr, lq, red);
-  if constexpr (NB > 0) s1_epilogue<NB>(accB, p, 1, n, tt, oy0, ox0, wave, lr, lq, red);
-  if constexpr (NC > 0) s1_epilogue<NC>(accC, p, 2, n, tt, oy0, ox0, wave, lr, lq, red);
+  if constexpr (NA > 0) s1_epilogue<NA, STATS>(accA, p, 0, n, tt, oy0, ox0, wave, lr, lq, red);
+  if constexpr (NB > 0) s1_epilogue<NB, STATS>(accB, p, 1, n, tt, oy0, ox0, wave, lr, lq, red);
+  if constexpr (NC > 0) s1_epilogue<NC, STATS>(accC, p, 2, n, tt, oy0, ox0, wave, lr, lq, red);
 }
 
 // dst[(G * nt_total + j) * 256 + lane * 4 + e]: G enumerates the MFMA groups of all chunks of one segment in consumption order
@@ -703,21 +708,22 @@ int cat_tconv_fwd(const cat_tconv_t* g, const float* pack, const float* bias, fl
   return cat::check_launch("tconv_fwd");
 }
 
-int cat_tstage1_fwd(const cat_tstage1_t* g, const float* x, const float* const* packs, const float* bias, float* y, float* stats,
-                    cat_stream_t stream) {
+static int tstage1_launch(const cat_tstage1_t* g, const float* x, const float* const* packs, const float* bias, float* const* ys,
+                          const int* ycs3, float* stats, const char* what, cat_stream_t stream) {
   CAT_REQUIRE(g->N > 0 && g->H > 0 && g->W > 0 && g->cin > 0 && (g->xcs & 3) == 0 && g->xcs >= g->cin, "tstage1: bad input geometry");
-  CAT_REQUIRE(y && stats && (g->ycs & 3) == 0 && (g->scs & 3) == 0, "tstage1: output / statistics buffers");
   CAT_REQUIRE((int64_t)g->N * g->H * g->W * g->xcs < (int64_t)4294967295LL, "tstage1: source larger than 2^32 elements");
   cat_pk::S1Args a{};
-  a.x = x; a.bias = bias; a.y = y; a.stats = stats;
-  a.xcs = g->xcs; a.c4 = (g->cin + 3) & ~3; a.N = g->N; a.H = g->H; a.W = g->W; a.reflect = g->reflect; a.ycs = g->ycs; a.scs = g->scs;
+  a.x = x; a.bias = bias; a.stats = stats;
+  a.xcs = g->xcs; a.c4 = (g->cin + 3) & ~3; a.N = g->N; a.H = g->H; a.W = g->W; a.reflect = g->reflect; a.scs = g->scs;
   int nt[3];
   double kflops = 0.0;
   for (int k = 0; k < 3; ++k) {
     nt[k] = g->width[k] > 0 ? cat::cdiv(g->width[k], 16) : 0;
     a.pack[k] = nt[k] ? packs[k] : x;     // a valid address for the (unused) buffer resource
+    a.ys[k] = ys[k]; a.ycs3[k] = ycs3[k];
     a.nt_total[k] = nt[k]; a.col0[k] = g->col0[k]; a.width[k] = g->width[k]; a.nvalid[k] = g->nvalid[k];
-    CAT_REQUIRE(nt[k] == 0 || (packs[k] && g->col0[k] + g->width[k] <= g->ycs && g->nvalid[k] <= g->width[k]), "tstage1: slice %d", k);
+    CAT_REQUIRE(nt[k] == 0 || (packs[k] && ys[k] && (ycs3[k] & 3) == 0 && g->col0[k] + g->width[k] <= ycs3[k] && g->nvalid[k] <= g->width[k]),
+                "tstage1: slice %d", k);
     const int ks = k == 0 ? 5 : (k == 1 ? 3 : 1);
     kflops += (double)g->nvalid[k] * ks * ks;
   }
@@ -731,12 +737,14 @@ int cat_tstage1_fwd(const cat_tstage1_t* g, const float* x, const float* const* 
   const int nmax = nt[0] > nt[1] ? (nt[0] > nt[2] ? nt[0] : nt[2]) : (nt[1] > nt[2] ? nt[1] : nt[2]);
   const size_t lds = (size_t)2 * a.tr * a.tc * cat_pk::PITCH * sizeof(float) + 6 * cat_pk::TABN * sizeof(int) + (size_t)8 * nmax * 16 * sizeof(float);
   hipStream_t s = (hipStream_t)stream;
-  cat::ProfScope prof("conv_tstage1", 2.0 * (double)g->N * g->H * g->W * g->cin * kflops, 0.0, stream);
+  cat::ProfScope prof(what, 2.0 * (double)g->N * g->H * g->W * g->cin * kflops, 0.0, stream);
 #define CAT_S1(NA, NB, NC)                                                                        \
   if (nt[0] == NA && nt[1] == NB && nt[2] == NC) {                                                \
-    cat_pk::tstage1_kernel<NA, NB, NC><<<(int)grid, 256, lds, s>>>(a);                            \
-    return cat::check_launch("tstage1_fwd");                                                      \
+    if (stats) cat_pk::tstage1_kernel<NA, NB, NC, true><<<(int)grid, 256, lds, s>>>(a);           \
+    else cat_pk::tstage1_kernel<NA, NB, NC, false><<<(int)grid, 256, lds, s>>>(a);                \
+    return cat::check_launch(what);                                                               \
   }
+  CAT_S1(1, 1, 1) CAT_S1(2, 1, 1) CAT_S1(1, 2, 1) CAT_S1(2, 2, 1)
   CAT_S1(1, 1, 2) CAT_S1(1, 1, 3) CAT_S1(1, 1, 4) CAT_S1(2, 1, 2) CAT_S1(2, 1, 3) CAT_S1(2, 1, 4)
   CAT_S1(1, 2, 2) CAT_S1(1, 2, 3) CAT_S1(1, 2, 4) CAT_S1(2, 2, 2) CAT_S1(2, 2, 3) CAT_S1(2, 2, 4)
 #undef CAT_S1
@@ -744,9 +752,28 @@ int cat_tstage1_fwd(const cat_tstage1_t* g, const float* x, const float* const* 
   return -22;
 }
 
+int cat_tstage1_fwd(const cat_tstage1_t* g, const float* x, const float* const* packs, const float* bias, float* y, float* stats,
+                    cat_stream_t stream) {
+  CAT_REQUIRE(y && stats && (g->ycs & 3) == 0 && (g->scs & 3) == 0, "tstage1: output / statistics buffers");
+  float* const ys[3] = {y, y, y};
+  const int ycs3[3] = {g->ycs, g->ycs, g->ycs};
+  return tstage1_launch(g, x, packs, bias, ys, ycs3, stats, "conv_tstage1", stream);
+}
+
 int cat_tstage1_supported(int w5, int w3, int w1) {
   const int a = cat::cdiv(w5, 16), b = cat::cdiv(w3, 16), c = cat::cdiv(w1, 16);
   return w5 > 0 && w3 > 0 && w1 > 0 && a <= 2 && b <= 2 && c >= 2 && c <= 4;
+}
+
+int cat_tstage1_dgrad(const cat_tstage1_t* g, const float* dy, const float* const* packs, float* const* dxs, const int* dxcs,
+                      cat_stream_t stream) {
+  CAT_REQUIRE(dxs && dxcs && !g->reflect, "tstage1 dgrad: zero-padded convolutions only, one output buffer per slot");
+  return tstage1_launch(g, dy, packs, nullptr, dxs, dxcs, nullptr, "conv_tstage1_dgrad", stream);
+}
+
+int cat_tstage1_dgrad_supported(int w5, int w3, int w1) {
+  const int a = cat::cdiv(w5, 16), b = cat::cdiv(w3, 16), c = cat::cdiv(w1, 16);
+  return w5 > 0 && w3 > 0 && w1 > 0 && a <= 2 && b <= 2 && c <= 4;
 }
 
 }  // extern "C"

@@ -34,6 +34,7 @@ _ENABLED = os.environ.get('CAT_FUSED_SPADE', '1') != '0'      # A/B switch; 'tra
 _ONLY = os.environ.get('CAT_FUSED_SPADE', '1') if os.environ.get('CAT_FUSED_SPADE', '1') in ('train', 'frozen') else None
 
 
+_S1_DGRAD = os.environ.get('CAT_FUSED_SPADE_S1_DGRAD', '1') != '0'     # A/B switch: the second convs' input gradients as one launch
 _UNITS = os.environ.get('CAT_FUSED_SPADE_UNITS', 'all')      # A/B switch: 'gb' / 'main' = only the gamma|beta nets / only the main units
 STATS = {'train_fwd': 0, 'frozen_fwd': 0, 'bwd': 0}      # calls per form (tests / diagnostics)
 
@@ -158,6 +159,13 @@ class _Plan:
             b['d2off'] = po
             po += tconv.pack_floats(b['k2'], self.cso, b['m'])
         self.dpack2 = z(po)
+        # the second convs' input gradients as ONE launch (cat_tstage1_dgrad: dT is staged once for the 5 x 5 and the 3 x 3 residual branch
+        # and the N-concatenated 1 x 1 second convs of the depthwise branches) where a kernel exists for the widths
+        r5, r3 = [b for b in res if b['k'] == 5], [b for b in res if b['k'] == 3]
+        self.s1d = None
+        if _S1_DGRAD and len(r5) == 1 and len(r3) == 1 and dws and L.query('cat_tstage1_dgrad_supported', r5[0]['w1'], r3[0]['w1'], self.hcd):
+            self.s1d = (r5[0], r3[0])
+            self.dpack2_dw = z(tconv.pack_floats(1, self.cso, self.hcd))
         po = 0
         for b in order:
             b['d1off'] = po
@@ -249,6 +257,8 @@ class _Plan:
             fwd.append(self._pack_job(b['conv2'].weight, self.pack2.data_ptr() + 4 * b['p2off'], tconv.FWD, self.Cout, b['m'], b['k2'], nt2, 0))
             bwd.append(self._pack_job(b['conv2'].weight, self.dpack2.data_ptr() + 4 * b['d2off'], tconv.DGRAD, b['m'], self.Cout, b['k2'], (b['m'] + 15) // 16, 0))
             bwd.append(self._pack_job(b['conv1'].weight, self.dpack1.data_ptr() + 4 * b['d1off'], tconv.DGRAD, self.Cin, b['m'], b['k'], nt1, 0))
+            if self.s1d is not None and b['kind'] == 'dw':
+                bwd.append(self._pack_job(b['conv2'].weight, self.dpack2_dw.data_ptr(), tconv.DGRAD, b['m'], self.Cout, 1, (self.hcd + 15) // 16, b['od']))
         for b in self.dws:
             if b['bn2'].weight is not None:
                 fwd.append(vec(self.gammad, b['od'], [b['bn2'].weight], b['m']))
@@ -520,8 +530,21 @@ class _UnitFn(torch.autograd.Function):
                 L.call('cat_conv2d_wgrad', C.byref(gw), xptr, ops._p(dt), ops._p(dst_), acc, ops._p(ws), sst)
             if res or not p.merge2:
                 put_side(b['conv2'].weight, kw)
+            if p.s1d is not None and (b is p.s1d[0] or b is p.s1d[1] or not res):
+                continue            # input gradient: the merged launch below
             seg = tconv.Segment(None, k2, k2 - 1 - pad2, False, b['d2off'], c4=p.cso, cin=p.Cout, xcs=p.cso, ptr=dt.data_ptr())
             tconv.run([seg], p.dpack2, None, None, m, n, h, w, h, w, ycs=dcs, ycw=w1, yptr=dst.data_ptr() + 4 * o)
+        if p.s1d is not None:
+            r5, r3 = p.s1d
+            gs = L.Stage1Geom()
+            gs.N, gs.H, gs.W, gs.xcs, gs.cin, gs.reflect, gs.ycs, gs.scs = n, h, w, p.cso, p.Cout, 0, 0, 0
+            packs, dxs, dxcs = (C.c_void_p * 3)(), (C.c_void_p * 3)(), (C.c_int * 3)(p.hc1, p.hc1, p.hcd)
+            for slot, (col0, width, nvalid, pk, dst) in enumerate(((r5['o1'], r5['w1'], r5['m'], p.dpack2.data_ptr() + 4 * r5['d2off'], da1),
+                                                                   (r3['o1'], r3['w1'], r3['m'], p.dpack2.data_ptr() + 4 * r3['d2off'], da1),
+                                                                   (0, p.hcd, sum(b['m'] for b in p.dws), p.dpack2_dw.data_ptr(), dad))):
+                gs.col0[slot], gs.width[slot], gs.nvalid[slot] = col0, width, nvalid
+                packs[slot], dxs[slot] = pk, dst.data_ptr()
+            L.call('cat_tstage1_dgrad', C.byref(gs), ops._p(dt), packs, dxs, dxcs, ops._stream())
         if p.merge2:
             def kw2(sst):
                 gw = ops._conv_geom(n, h, w, p.hcd, p.hcd, h, w, p.Cout, p.cso, 1, 1, 1, 0, L.PAD_ZERO, wcs=p.hcd)

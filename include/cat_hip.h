@@ -382,6 +382,15 @@ int cat_tstage1_supported(int w5, int w3, int w1);
 int cat_tstage1_fwd(const cat_tstage1_t* g, const float* x, const float* const* packs, const float* bias, float* y, float* stats,
                     cat_stream_t stream);
 
+/* Input gradients of the branches' SECOND convs in one launch (autograd of inception_modules.py:471-489 / 549-562, zero padding): the same
+ * kernel reading dy -- slot 0 = the 5 x 5 residual branch, slot 1 = the 3 x 3 one, slot 2 = the N-concatenated 1 x 1 second convs of the
+ * depthwise branches -- with transposed / flipped filter streams (cat_prep_run kind 0 mode 1); slot k writes columns
+ * [col0[k], col0[k] + width[k]) of its OWN buffer dxs[k] with pixel stride dxcs[k] (the hidden-activation gradients live in two tensors).
+ * g->ycs / scs / reflect are ignored (no statistics, no bias). */
+int cat_tstage1_dgrad_supported(int w5, int w3, int w1);
+int cat_tstage1_dgrad(const cat_tstage1_t* g, const float* dy, const float* const* packs, float* const* dxs, const int* dxcs,
+                      cat_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -462,7 +462,7 @@ def test_spade_distill_step_mse_adaptors():
 
 
 @pytest.mark.parametrize('fin,fout,channels,owned', [(48, 24, None, False), (24, 24, None, False), (40, 16, [30, 6, 12], False),
-                                                     (40, 16, [30, 6, 12], True), (24, 24, [6, 6, 6], True)])
+                                                     (40, 16, [30, 6, 12], True), (24, 24, [6, 6, 6], True), (40, 16, [96, 36, 60], True)])
 def test_fused_spade_units_match_general_path(fin, fout, channels, owned):
     """cat_amd/fused_spade.py: the gamma|beta net of InceptionSPADE and the main six-branch unit of SPADEInvertedResidualChannels as 5
     launches each (train-mode SyncBN on one rank, zero padding, C_in != C_out, learned / identity shortcut as the epilogue addend) against
