@@ -1,7 +1,7 @@
 set -x
 export TMPDIR=/tmp
 O=$PWD/gpurun_out/validate; mkdir -p $O
-( time timeout 1500 python -m pytest tests -m gpu -x -q -p no:cacheprovider ) > $O/pytest.log 2>&1; echo "pytest rc $?" >> $O/pytest.log
+( time timeout 1500 python -m pytest ${VALIDATE_TESTS:-tests} -m gpu -x -q -p no:cacheprovider ) > $O/pytest.log 2>&1; echo "pytest rc $?" >> $O/pytest.log
 tail -6 $O/pytest.log
 python -c 'import __graft_entry__ as g; g.smoke()' > $O/smoke.log 2>&1; tail -1 $O/smoke.log
 python bench.py --workload spade > $O/bench_spade.json 2> $O/bench_spade.err
