@@ -31,6 +31,7 @@ from . import optim
 from . import tconv
 
 _ENABLED = os.environ.get('CAT_FUSED_BLOCK', '1') != '0'
+_MERGE_DW_DGRAD = os.environ.get('CAT_FUSED_BLOCK_MERGE_DW_DGRAD', '1') != '0'     # A/B switch
 _BACKWARD_READY = True
 
 
@@ -150,6 +151,8 @@ class _Plan:
             b['d2off'] = po
             po += tconv.pack_floats(b['k2'], self.cs, b['m'])
         self.dpack2 = z(po)
+        # ... the 1 x 1 second convs of the depthwise branches N-concatenated: their input gradients are ONE launch over dT into dAd
+        self.dpack2_dw = z(tconv.pack_floats(1, self.cs, self.hcd)) if (_MERGE_DW_DGRAD and len(dws) > 1) else None
         po = 0
         for b in order:
             b['d1off'] = po
@@ -236,6 +239,8 @@ class _Plan:
             fwd.append(self._pack_job(b['conv2'].weight, self.pack2.data_ptr() + 4 * b['p2off'], tconv.FWD, self.C, b['m'], b['k2'], nt2, 0))
             bwd.append(self._pack_job(b['conv2'].weight, self.dpack2.data_ptr() + 4 * b['d2off'], tconv.DGRAD, b['m'], self.C, b['k2'], (b['m'] + 15) // 16, 0))
             bwd.append(self._pack_job(b['conv1'].weight, self.dpack1.data_ptr() + 4 * b['d1off'], tconv.DGRAD, self.C, b['m'], b['k'], nt2, 0))
+            if self.dpack2_dw is not None and b['kind'] == 'dw':
+                bwd.append(self._pack_job(b['conv2'].weight, self.dpack2_dw.data_ptr(), tconv.DGRAD, b['m'], self.C, 1, (self.hcd + 15) // 16, b['od']))
         for b in self.dws:
             if b['bn2'].weight is not None:
                 fwd.append(vec(self.gammad, b['od'], [b['bn2'].weight], b['m']))
@@ -487,6 +492,8 @@ class _BlockFn(torch.autograd.Function):
                 L.call('cat_conv2d_wgrad', C.byref(gw), xptr, ops._p(dt), ops._p(dst_), acc, ops._p(ws), sst)
             if res or not p.merge2:
                 put_side(conv2.weight, kw)
+            if not res and p.dpack2_dw is not None:
+                continue            # input gradient: the merged launch below
             seg_pad = k2 - 1 - (0 if mode2 == L.PAD_REFLECT else pad2)
             seg = tconv.Segment(None, k2, seg_pad, False, b['d2off'], c4=p.cs, cin=c, xcs=p.cs, ptr=dt.data_ptr())
             if mode2 == L.PAD_REFLECT:
@@ -495,6 +502,9 @@ class _BlockFn(torch.autograd.Function):
                 L.call('cat_reflect_pad_bwd2', ops._p(dxp), w1, C.c_void_p(dst.data_ptr() + 4 * o), dcs, None, 0, n, h, w, w1, pad2, st)
             else:
                 tconv.run([seg], p.dpack2, None, None, m, n, h, w, h, w, ycs=dcs, ycw=w1, yptr=dst.data_ptr() + 4 * o)
+        if ctx.has_dw and p.dpack2_dw is not None:
+            seg = tconv.Segment(None, 1, 0, False, 0, c4=p.cs, cin=c, xcs=p.cs, ptr=dt.data_ptr())
+            tconv.run([seg], p.dpack2_dw, None, None, p.hcd, n, h, w, h, w, ycs=p.hcd, ycw=p.hcd, yptr=dad.data_ptr(), nvalid=sum(b['m'] for b in p.dws))
         if p.merge2:      # d W2 of all depthwise branches: dT^T x Ad as ONE 1x1 weight-gradient launch over the concatenated hidden buffer
             def kw2(sst):
                 gw = ops._conv_geom(n, h, w, p.hcd, p.hcd, h, w, c, p.cs, 1, 1, 1, 0, L.PAD_ZERO, wcs=p.hcd)
