@@ -47,6 +47,11 @@ bool twgrad_applicable(const cat_conv_t* g);
 int twgrad_nblk(const cat_conv_t* g);
 int twgrad(const cat_conv_t* g, const float* x, const float* dy, float* ws, hipStream_t s);   // partials [nblk][Cout][taps * round_up(Cin, 4)]
 
+// pixel-streaming weight gradient of 1 x 1 layers with few channels and many pixels (conv_pwgrad.hip)
+bool pwgrad_applicable(const cat_conv_t* g);
+int pwgrad_nblk(const cat_conv_t* g);
+int pwgrad(const cat_conv_t* g, const float* x, const float* dy, float* ws, hipStream_t s);   // partials [nblk][Cout][round_up(Cin, 4)]
+
 // Opt a kernel in to more than 64 KB of dynamic LDS.  hipFuncSetAttribute applies to the CURRENT device only, so the "already
 // done" flag of a call site is kept per device ordinal (a process may drive several GPUs, e.g. the 2-ranks-on-one-box tests).
 struct LdsOptIn {

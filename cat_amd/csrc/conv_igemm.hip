@@ -2002,6 +2002,7 @@ size_t cat_conv2d_wgrad_ws_bytes(const cat_conv_t* g) {
   const size_t K = (size_t)g->kh * g->kw * ((g->Cin + 3) & ~3);
   if (cat::smallco_applicable(g)) return (size_t)cat::smallco_wgrad_nblk(g) * g->Cout * K * sizeof(float);
   if (cat::twgrad_applicable(g)) return (size_t)cat::twgrad_nblk(g) * g->Cout * K * sizeof(float);
+  if (cat::pwgrad_applicable(g)) return (size_t)cat::pwgrad_nblk(g) * g->Cout * K * sizeof(float);
   return (size_t)pl.nsplit * g->Cout * K * sizeof(float);
 }
 
@@ -2038,6 +2039,14 @@ int cat_conv2d_wgrad(const cat_conv_t* g, const float* x, const float* dy, float
     const int64_t total = (int64_t)a.Cout * a.kh * a.kw * (a.c4 / 4);
     wgrad_reduce_kernel<<<(int)((total + 15) / 16), 256, 0, s>>>((const float*)ws, dw, cat::twgrad_nblk(g), a.Cout, a.kh * a.kw, a.cval, a.wcs, a.c4,
                                                                   a.K, accumulate);
+    return cat::check_launch("conv2d_wgrad_reduce");
+  }
+  if (cat::pwgrad_applicable(g)) {
+    CAT_REQUIRE(ws != nullptr, "conv wgrad: workspace required");
+    cat::ProfScope prof("conv_pwgrad", prof_flops, 0.0, stream);
+    if (int e = cat::pwgrad(g, x, dy, (float*)ws, s)) return e;
+    const int64_t total = (int64_t)a.Cout * (a.c4 / 4);
+    wgrad_reduce_kernel<<<(int)((total + 15) / 16), 256, 0, s>>>((const float*)ws, dw, cat::pwgrad_nblk(g), a.Cout, 1, a.cval, a.wcs, a.c4, a.K, accumulate);
     return cat::check_launch("conv2d_wgrad_reduce");
   }
   int rows_per = 0;

@@ -81,6 +81,13 @@ CONV_CASES = [
     (3, 64, 4, 2, 1, False, 2, 2, 70, 50),
     (6, 20, 4, 2, 1, False, 0, 1, 33, 37),
     (6, 128, 4, 2, 1, False, 2, 2, 64, 96),
+    # 1 x 1 layers with few channels over many pixels: the pixel-streaming weight gradient (csrc/conv_pwgrad.hip) -- two 64-channel groups
+    # of x, a pixel count that is no multiple of the 32-pixel step, 65 .. 128 output channels (two accumulator groups), three x groups
+    (77, 60, 1, 1, 0, False, 0, 4, 64, 64),
+    (12, 16, 1, 1, 0, False, 0, 5, 50, 70),
+    (36, 100, 1, 1, 0, False, 0, 2, 96, 96),
+    (130, 7, 1, 1, 0, False, 0, 1, 128, 130),
+    (4, 64, 1, 1, 0, False, 0, 3, 61, 67),
 ]
 
 
@@ -112,6 +119,23 @@ def test_conv2d_fwd_bwd(dev, cin, cout, k, stride, pad, reflect, act, n, h, w):
     assert rel(xg.grad, xr.grad) < TOL
     assert rel(wg.grad, wr.grad) < TOL
     assert rel(bg.grad, br.grad) < TOL
+
+
+def test_pointwise_wgrad_takes_the_streaming_kernel(dev):
+    """The 1 x 1 cases above must run cat_pw::pwgrad_kernel (family conv_pwgrad), not fall through to the general kernel."""
+    from cat_amd import _lib, ops
+    lib = _lib.load()
+    lib.cat_prof_enable(1)
+    try:
+        x = _nhwc(detfill.normal((4, 12, 64, 64), 1), dev, True)
+        wg = _cl(detfill.normal((16, 12, 1, 1), 2), dev)
+        y = ops.Conv2dFn.apply(x, wg, None, 1, 0, 0, 0, 0.2)
+        y.backward(_nhwc(detfill.normal((4, 16, 64, 64), 3), dev))
+        torch.cuda.synchronize()
+        fam = _families()
+    finally:
+        lib.cat_prof_enable(0)
+    assert fam.get('conv_pwgrad', 0) == 1, fam
 
 
 def _families():
