@@ -43,6 +43,20 @@ def test_weights_are_channels_last_after_flatten_rules():
     assert ops.weight_wcs(ref) is None                                               # plain NCHW-contiguous is not
 
 
+def test_weight_stride_of_single_row_and_single_channel_weights():
+    """ops.weight_wcs for the layouts whose strides do not tell: a [1][I][1][1] row is padded only if its storage holds the padded row
+    (FusedAdam re-houses the dense one), and a one-input-channel weight [O][1][1][1] has row stride 1 -- what the fused blocks' gradient
+    scatter must respect (round 3: it wrote cs4 = 4 columns per row there and overwrote the next parameter's first gradient entry)."""
+    from cat_amd import ops
+    assert ops.weight_wcs(torch.zeros(1, 6, 1, 1)) is None                                # dense row, 6 floats of storage: not the padded layout
+    assert ops.weight_wcs(torch.zeros(1, 8, 1, 1)) == 8
+    padded = ops.padded_weight_like((1, 6, 1, 1), 'cpu')
+    assert ops.weight_wcs(padded) == 8 and padded.shape == (1, 6, 1, 1)
+    one = torch.zeros(6, 1, 1, 1)
+    assert ops.weight_wcs(one) == 1                                                       # what FusedAdam keeps for shape[1] == 1
+    assert ops.weight_wcs(ops.padded_weight_like((6, 1, 1, 1), 'cpu')) == 4
+
+
 def test_factory_and_flags():
     from cat_amd.distillers import find_distiller_using_name, get_option_setter
     cls = find_distiller_using_name('inception')
