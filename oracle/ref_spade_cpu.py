@@ -28,7 +28,12 @@ def sync_bn(sd, p, x, training, synced=False, act=None):
     synced=True : the multi-replica training path on the WHOLE (gathered) batch: sum / square-sum -> mean, biased variance
                   clamped at eps (not +eps, :140), running stats with the unbiased variance (:132-137)."""
     w, b = sd.get(p + '.weight'), sd.get(p + '.bias')
-    rm, rv = sd[p + '.running_mean'], sd[p + '.running_var']
+    rm, rv = sd.get(p + '.running_mean'), sd.get(p + '.running_var')
+    if rm is None:
+        # norm_G = 'spadeinstance...' (inception_modules.py:414-415): the layer is nn.InstanceNorm2d (no running statistics in the
+        # state dict, per-sample statistics in train and eval mode alike); its affine form carries weight / bias
+        y = F.instance_norm(x, weight=w, bias=b, eps=EPS)
+        return F.relu(y) if act == 'relu' else y
     if not (training and synced):
         y = F.batch_norm(x, rm, rv, w, b, training, MOMENTUM, EPS)
     else:

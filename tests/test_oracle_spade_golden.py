@@ -123,3 +123,26 @@ def check_step_grads(g, tag, grads, params, seed, tol):
         solid = np.abs(ref) > 10 * tol * gmax
         if solid.any():
             np.testing.assert_allclose(d_got[solid], d_ref[solid], rtol=5e-2, atol=1e-7)
+
+
+def test_spadeinstance_generator_forward_and_gradients():
+    """norm_G='spadeinstance3x3' (reference inception_modules.py:407-423; no launch script uses it): the block's hidden / shortcut norms and
+    the SPADE layers' param-free norm are InstanceNorm2d -- recognised by the oracle from the state dict (no running statistics) -- while the
+    gamma|beta nets keep SynchronizedBatchNorm2d.  Train-mode forward, five parameter gradients and the SyncBN statistics vs the reference."""
+    g = H.load('spade_instance_fwd.npz')
+    sd = detfill.fill_state_dict(H.sd_from_shapes(g['shapes']), 701, gamma_abs_normal=True)
+    assert 'head_0.spade.param_free_norm.running_mean' not in sd and 'head_0.spade.res_ops.0.0.norm.running_mean' in sd
+    assert sorted(k for k in sd if 'running' in k) == json.loads(str(g['state_after']))
+    names = [k[5:] for k in g.files if k.startswith('grad:')]
+    for k in names:
+        sd[k].requires_grad_(True)
+    lab, ins = torch.from_numpy(g['label'].astype(np.int64)), torch.from_numpy(g['instance'])
+    sem = R.preprocess_input(lab, ins, 5)
+    y, _ = R.inception_spade_generator(sd, sem, dict(crop_size=256, aspect_ratio=2.0, num_upsampling_layers='more'), training=True)
+    _close(_checks(y), g['y_checks'], 1e-4)
+    _close(y.detach()[:, :, ::2, ::2].numpy(), g['y_sub'], 1e-4)
+    (y * detfill.normal(tuple(y.shape), 712)).sum().backward()
+    for k in names:
+        _close(sd[k].grad.numpy(), g['grad:' + k], 2e-3)
+    for k in (f[4:] for f in g.files if f.startswith('buf:')):
+        _close(sd[k].detach().numpy(), g['buf:' + k], 1e-5)

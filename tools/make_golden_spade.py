@@ -297,3 +297,39 @@ if __name__ == '__main__' and os.environ.get('GOLDEN_TRANSFER', '1') == '1':
 
 if __name__ == '__main__' and os.environ.get('GOLDEN_SHRINK', '1') == '1':
     shrink_golden()
+
+
+def spadeinstance_golden():
+    """norm_G = 'spadeinstance3x3' (inception_modules.py:407-423: the block's hidden norms, its shortcut norm and the SPADE layers' param-free
+    norm become nn.InstanceNorm2d; the gamma|beta nets keep SynchronizedBatchNorm2d, :598): one train-mode generator forward + the gradient of
+    sum(out * g) w.r.t. four parameters, ngf 6, 2 x 128 x 256, seeded weights.  No launch script uses the option; the vectors pin the oracle
+    (and, once built, the HIP path) for it."""
+    opt = spade_opt(data_height=128, data_width=256, data_channel=6)
+    o = copy.deepcopy(opt)
+    o.ngf, o.norm_G = 6, 'spadeinstance3x3'
+    G = networks.define_G(opt.input_nc, 3, 6, 'inception_spade', 'instance', 0, 'xavier', 0.02, [], opt=o)
+    G.load_state_dict(detfill.fill_state_dict(G.state_dict(), 701, gamma_abs_normal=True))
+    G.train()
+    h, w, n = 128, 256, 2
+    lab, ins, img = synth_inputs(n, h, w, opt.input_nc, 711)
+    sm = SPADEModel.__new__(SPADEModel)
+    sm.opt, sm.device = opt, torch.device('cpu')
+    sem, _ = sm.preprocess_input({'label': torch.from_numpy(lab).float(), 'instance': torch.from_numpy(ins), 'image': img})
+    out = {'shapes': shapes_json(G.state_dict()), 'label': lab.astype(np.int16), 'instance': ins, 'h': h, 'w': w, 'n': n}
+    y = G(sem)
+    g = detfill.normal(tuple(y.shape), 712)
+    (y * g).sum().backward()
+    out['y_sub'] = y.detach()[:, :, ::2, ::2].contiguous().numpy()
+    out['y_checks'] = checks(y)
+    params = dict(G.named_parameters())
+    for k in ('fc.weight', 'head_0.res_ops.1.0.norm.weight', 'up_2.spade.dw_ops.1.0.conv.weight', 'up_3.shortcut.0.weight', 'up_3.dw_ops.0.2.conv.weight'):
+        out['grad:' + k] = params[k].grad.numpy().copy()
+    out['state_after'] = json.dumps(sorted(k for k in G.state_dict() if 'running' in k))      # only the SyncBN layers carry statistics
+    for k in ('fc_norm.running_mean', 'up_3.spade.res_ops.0.0.norm.running_var'):
+        out['buf:' + k] = G.state_dict()[k].numpy().copy()
+    np.savez_compressed(os.path.join(OUT, 'spade_instance_fwd.npz'), **out)
+    print('spade_instance_fwd.npz', tuple(y.shape), len(params), 'parameters')
+
+
+if __name__ == '__main__' and os.environ.get('GOLDEN_INSTANCE', '1') == '1':
+    spadeinstance_golden()
