@@ -37,6 +37,23 @@ class TConv(C.Structure):
                                                                                             ('seg', TSeg * TCONV_MAXSEG)]
 
 
+QCONV_MAXSEG = 8
+
+
+class QSeg(C.Structure):
+    _fields_ = [('src', c_p), ('scale', c_p), ('shift', c_p)] + [(n, c_i) for n in ('sstride', 'xcs', 'c4', 'cin', 'kh', 'kw', 'oy', 'ox', 'act')] + \
+               [('slope', c_f), ('reflect', c_i), ('pack_off', c_i)]
+
+
+class QConv(C.Structure):
+    _fields_ = [('res', c_p), ('stats', c_p)] + [(n, c_i) for n in ('rcs', 'scs', 'N', 'H', 'W', 'Ho', 'Wo', 'S', 'OS', 'ncls', 'Nn', 'ycs', 'ycw', 'nvalid',
+                                                                    'act')] + [('slope', c_f), ('nseg', c_i), ('seg', QSeg * QCONV_MAXSEG)]
+
+
+class QPlan(C.Structure):
+    _fields_ = [(n, c_i) for n in ('cs', 'nq', 'nsplit', 'th', 'tw', 'tiles')] + [('pack_floats', c_l)]
+
+
 TNORM_MAXSLICE, DWM_MAXQ, PREP_MAXSRC = 8, 24, 8
 DWM_MAXQ_BWD = 16
 
@@ -87,6 +104,11 @@ SIGNATURES = {
     'cat_tstage1_dgrad_supported': (c_i, [c_i, c_i, c_i]),
     'cat_tstage1_dgrad': (c_i, [C.POINTER(Stage1Geom), c_p, c_p, c_p, c_p, c_p]),
     'cat_tnorm_finalize': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_i, c_p]),
+    'cat_tnorm_finalize2': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_i, c_p]),
+    'cat_qconv_min_tiles16': (c_i, [c_i]),
+    'cat_qconv_plan': (c_i, [C.POINTER(QConv), C.POINTER(QPlan)]),
+    'cat_qconv_pack': (c_i, [C.POINTER(QConv), c_i, c_p, c_p, c_i, C.POINTER(c_i), c_i, c_i, c_i, c_p]),
+    'cat_qconv_fwd': (c_i, [C.POINTER(QConv), c_p, c_p, c_p, c_p]),
     'cat_reflect_pad_bwd2': (c_i, [c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     'cat_affine_res_fwd': (c_i, [c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_p]),
     'cat_dwm_fwd': (c_i, [C.POINTER(DwmGeom), c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),

@@ -24,7 +24,7 @@ struct FinArgs {
 
 // grid (cdiv(cs, 4), G), one wave per channel; part[((g * tiles + t) * 2 + {0,1}) * scs + c]
 __global__ __launch_bounds__(256) void tnorm_finalize_kernel(const float* __restrict__ part, int scs, int tiles, int tiles_x, int Ho, int Wo,
-                                                             int imgs_per_group, const float* __restrict__ gamma,
+                                                             int th, int tw, int ncls, int imgs_per_group, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, FinArgs fa, float eps, float momentum,
                                                              float* __restrict__ scale, float* __restrict__ shift,
                                                              float* __restrict__ mean_out, float* __restrict__ rstd_out, int cs,
@@ -59,13 +59,13 @@ __global__ __launch_bounds__(256) void tnorm_finalize_kernel(const float* __rest
   }
   for (int t = lane + 64 * R; t < ntile; t += 64) s += pg[(int64_t)t * 2 * scs];
   s = cat::wave_sum(s);
-  const float count = (float)Ho * (float)Wo * (float)imgs_per_group;
+  const float count = (float)Ho * (float)Wo * (float)ncls * (float)imgs_per_group;
   const float mean = s / count;
   float m2 = 0.f;
   auto tile_n = [&](int t) {
-    const int ti = t % per_img;
+    const int ti = (t % per_img) / ncls;      // `tiles` counts entries per image: lattice tiles x classes
     const int ty = ti / tiles_x, tx = ti - ty * tiles_x;
-    return (float)(min(TH, Ho - ty * TH) * min(TW, Wo - tx * TW));
+    return (float)(min(th, Ho - ty * th) * min(tw, Wo - tx * tw));
   };
 #pragma unroll
   for (int r = 0; r < R; ++r) {
@@ -277,9 +277,9 @@ __global__ __launch_bounds__(256) void dwm_fwd_kernel(DwmArgs p) {
 
 extern "C" {
 
-int cat_tnorm_finalize(const float* part, int scs, int G, int N, int Ho, int Wo, const float* gamma, const float* beta, int nslices,
-                       const cat_nslice_t* slices, float eps, float momentum, float* scale, float* shift, float* mean, float* rstd,
-                       int mstride, cat_stream_t stream) {
+int cat_tnorm_finalize2(const float* part, int scs, int G, int N, int Ho, int Wo, int th, int tw, int ncls, const float* gamma,
+                        const float* beta, int nslices, const cat_nslice_t* slices, float eps, float momentum, float* scale, float* shift,
+                        float* mean, float* rstd, int mstride, cat_stream_t stream) {
   CAT_REQUIRE(G == 1 || G == N, "tnorm finalize: groups must be 1 (batch norm) or N (instance norm)");
   CAT_REQUIRE(nslices >= 1 && nslices <= CAT_TNORM_MAXSLICE && (scs & 3) == 0, "tnorm finalize: %d slices", nslices);
   FinArgs fa{};
@@ -288,10 +288,17 @@ int cat_tnorm_finalize(const float* part, int scs, int G, int N, int Ho, int Wo,
     fa.sl[k] = slices[k];
     CAT_REQUIRE(slices[k].c0 >= 0 && slices[k].c > 0 && slices[k].c0 + slices[k].c <= scs, "tnorm finalize: slice %d outside the table", k);
   }
-  const int tiles_x = cdiv(Wo, TW), tiles = tiles_x * cdiv(Ho, TH);
-  tnorm_finalize_kernel<<<dim3(cdiv(scs, 4), G), 256, 0, (hipStream_t)stream>>>(part, scs, tiles, tiles_x, Ho, Wo, G == 1 ? N : 1, gamma, beta, fa,
-                                                                                  eps, momentum, scale, shift, mean, rstd, scs, mstride);
+  CAT_REQUIRE(th > 0 && tw > 0 && ncls >= 1, "tnorm finalize: tile geometry");
+  const int tiles_x = cdiv(Wo, tw), tiles = tiles_x * cdiv(Ho, th) * ncls;
+  tnorm_finalize_kernel<<<dim3(cdiv(scs, 4), G), 256, 0, (hipStream_t)stream>>>(part, scs, tiles, tiles_x, Ho, Wo, th, tw, ncls, G == 1 ? N : 1, gamma,
+                                                                                  beta, fa, eps, momentum, scale, shift, mean, rstd, scs, mstride);
   return cat::check_launch("tnorm_finalize");
+}
+
+int cat_tnorm_finalize(const float* part, int scs, int G, int N, int Ho, int Wo, const float* gamma, const float* beta, int nslices,
+                       const cat_nslice_t* slices, float eps, float momentum, float* scale, float* shift, float* mean, float* rstd,
+                       int mstride, cat_stream_t stream) {
+  return cat_tnorm_finalize2(part, scs, G, N, Ho, Wo, TH, TW, 1, gamma, beta, nslices, slices, eps, momentum, scale, shift, mean, rstd, mstride, stream);
 }
 
 int cat_affine_res_fwd(const float* x, int xcs, const float* scale, const float* shift, int sstride, const float* res, int rcs, float* y,

@@ -24,6 +24,7 @@
 // [lane][4]: one coalesced 1 KB global_load_dwordx4 per wave, no address arithmetic on the vector ALU, which on gfx950 shares
 // its issue slots with the fp32 MFMA).  Filters of trainable layers are re-packed once per optimizer step.
 #include "common.h"
+#include <stdio.h>
 #include <stdlib.h>
 
 namespace cat_pk {
@@ -672,7 +673,13 @@ int cat_tconv_fwd(const cat_tconv_t* g, const float* pack, const float* bias, fl
   const int tw = g->stats ? 16 : (tw_env ? tw_env : (wg16 >= tw32_minwg && nt <= tw32_maxnt ? 32 : 16));
   CAT_REQUIRE(tw == 16 || tw == 32, "tconv: CAT_PK_TW must be 16 or 32");
   CAT_REQUIRE(g->stats == nullptr || (g->act == CAT_ACT_NONE && g->res == nullptr && g->scs >= g->ycw), "tconv: statistics need a plain epilogue");
-  L.ablate = getenv("CAT_PK_ABLATE") ? atoi(getenv("CAT_PK_ABLATE")) : 0;
+  // diagnostic switch (tools/debug/tconv_ablate.py): read ONCE per process, and loud -- a non-zero value makes the results wrong by design
+  static const int ablate_env = [] {
+    const int v = getenv("CAT_PK_ABLATE") ? atoi(getenv("CAT_PK_ABLATE")) : 0;
+    if (v) fprintf(stderr, "libcat_hip: CAT_PK_ABLATE=%d -- tconv results are INTENTIONALLY WRONG (timing diagnostics only)\n", v);
+    return v;
+  }();
+  L.ablate = ablate_env;
   L.hl = hl;
   L.tr = cat_pk::TH + hl + hr;
   L.tc = tw + hl + hr;

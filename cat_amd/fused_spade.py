@@ -85,18 +85,33 @@ def applicable(res_ops, dw_ops, x, training):
     n, c, h, w = x.shape
     if not ops.tconv_applicable(n, h, w, 16, 3, 3, 1, 1):
         return False
+    if c == 1:      # FusedAdam stores [m][1][1][1] weights unpadded (row stride 1): the merged first-conv gradient scatter writes cs4(Cin)-wide rows
+        return False
     res, dws = _branches(res_ops, dw_ops)
+    first = (res + dws)[0]
+    act0 = cnn._act_code(first['act'])
     for b in res + dws:
-        convs = [b['conv1'], b['conv2']] + ([b['dconv']] if b['kind'] == 'dw' else [])
-        if any('weight_orig' in cv._parameters or cv.stride[0] != 1 for cv in convs):      # spectral norm: general path
+        dw = b['kind'] == 'dw'
+        convs = [b['conv1'], b['conv2']] + ([b['dconv']] if dw else [])
+        if any('weight_orig' in cv._parameters or cv.stride[0] != 1 or cv.dilation != (1, 1) or cv.padding_mode != 'zeros' for cv in convs):
+            return False      # spectral norm / strides / dilation: general path
+        if b['conv1'].groups != 1 or b['conv2'].groups != 1 or (dw and b['dconv'].groups != b['m']):
             return False
-        norms = [b['bn1']] + ([b['bn2']] if b['kind'] == 'dw' else [])
+        norms = [b['bn1']] + ([b['bn2']] if dw else [])
         if any(not isinstance(nm, cnn.BatchNorm2d) or nm.training != training or not nm.track_running_stats or nm.momentum is None for nm in norms):
             return False
-        if cnn._act_code(b['act'])[0] not in (L.ACT_RELU, L.ACT_LRELU):
+        # the plan keeps ONE (eps, momentum, activation) for the whole unit and assumes 'same' zero padding everywhere
+        if any(float(nm.eps) != float(first['bn1'].eps) or float(nm.momentum) != float(first['bn1'].momentum) for nm in norms):
             return False
+        if cnn._act_code(b['act']) != act0 or act0[0] not in (L.ACT_RELU, L.ACT_LRELU):
+            return False
+        k2 = 1 if dw else b['k']
         ks = [b['k'], b.get('kd', 1), b['conv2'].kernel_size[0]]
-        if any(k not in (1, 3, 5) for k in ks) or b['conv1'].padding[0] != (b['k'] - 1) // 2:
+        if any(k not in (1, 3, 5) for k in ks) or b['conv2'].kernel_size[0] != k2:
+            return False
+        if b['conv1'].padding[0] != (b['k'] - 1) // 2 or b['conv2'].padding[0] != (k2 - 1) // 2:
+            return False
+        if dw and b['dconv'].padding[0] != (b.get('kd', 1) - 1) // 2:
             return False
     if sum(_cs4(b['m']) for b in dws) > 4 * (L.DWM_MAXQ_BWD if training else L.DWM_MAXQ):
         return False

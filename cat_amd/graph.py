@@ -110,6 +110,10 @@ class GraphedDPStep:
     def __init__(self, model, example_batch, warmup=3):
         if not hasattr(model, '_dp_first'):
             raise RuntimeError('GraphedDPStep: needs an InceptionDistiller')
+        if getattr(model, 'dp', None) is not None and not getattr(model, 'dp_overlap', True):
+            # the segments ARE the overlapped schedule (deferred Adam G, teacher on the side stream); a model configured with
+            # enable_data_parallel(overlap=False) keeps its eager serial schedule -- callers fall back to plain model.optimize_parameters
+            raise RuntimeError('GraphedDPStep: the model was configured with dp_overlap=False; its serial schedule is launched eagerly')
         self.model = model
         self.dp = getattr(model, 'dp', None) is not None
         dev = model.device

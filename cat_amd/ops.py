@@ -247,8 +247,12 @@ def weight_wcs(w):
     o, i, kh, kw = w.shape
     s0, s1, s2, s3 = w.stride()
     wcs = s3 if kw > 1 else (s2 if kh > 1 else (s0 if o > 1 else cs_for(i)))
-    if o == 1 and kh == 1 and kw == 1 and wcs != i and w.untyped_storage().nbytes() // 4 - w.storage_offset() < wcs:
-        return None      # a dense [1][I] row (I % 4 != 0): the strides of a single row cannot tell, its storage can -- not padded
+    if o == 1 and kh == 1 and kw == 1 and wcs != i:
+        # a single [1][I] row with I % 4 != 0: only the strides of the size-1 dims tell a padded row (padded_weight_like / FusedAdam views keep
+        # s0 = s2 = s3 = round_up(I, 4)) from a dense one (a test tensor, a checkpoint tensor, a slice of a larger storage: s3 = 1 or I) -- never
+        # inferred from what happens to lie behind the row in its storage.  Dense rows are re-laid-out by weight_cl
+        if not (s0 == wcs and s2 == wcs and s3 == wcs) or w.untyped_storage().nbytes() // 4 - w.storage_offset() < wcs:
+            return None
     ok = wcs >= i and (i == 1 or s1 == 1) and (kw == 1 or s3 == wcs) and (kh == 1 or s2 == kw * wcs) and (o == 1 or s0 == kh * kw * wcs)
     return wcs if ok else None
 

@@ -75,17 +75,49 @@ def backend_version():
     return b
 
 
+def _watchdog_retired_all():
+    """True once ProcessGroupNCCL's watchdog has retired every collective this process enqueued: its `pg_status` (part of the flight-recorder
+    dump, maintained by the watchdog thread itself) reports last_completed_collective == last_enqueued_collective for every group.
+    None if this torch build does not expose the status (the caller then falls back to waiting a few polling periods)."""
+    import pickle
+    try:
+        from torch._C import _distributed_c10d as c10d
+        status = pickle.loads(c10d._dump_nccl_trace(includeCollectives=False, includeStackTraces=False, onlyActive=True)).get('pg_status')
+        if not status:
+            return None
+        for st in status.values():
+            if int(st['last_completed_collective']) < int(st['last_enqueued_collective']):
+                return False
+        return True
+    except Exception:      # noqa: BLE001  (diagnostic API: any surprise means "unknown")
+        return None
+
+
 def settle_collectives(seconds=None):
     """Call before a hipGraph capture in a process that has issued RCCL collectives.  ProcessGroupNCCL's watchdog thread polls the events of
     collectives it has not yet seen complete (every ~100 ms); a poll that lands inside a stream capture is refused by the HIP runtime
     (hipErrorCapturedEvent: "operation not permitted on an event last recorded in a capturing stream") and the watchdog takes the process
     down -- observed with a world_size-1 group when the capture started right after the warm-up steps.  After a device synchronize every
-    collective HAS completed; a few polling periods let the watchdog retire them."""
+    collective HAS completed on the GPU; what is waited for here is the WATCHDOG having retired them, observed through its own bookkeeping
+    (`_watchdog_retired_all`: a handshake, not a timing assumption; bounded by CAT_DP_CAPTURE_SETTLE_MAX_S, default 30 s).  Only where that status is not
+    available does the fixed CAT_DP_CAPTURE_SETTLE_S wait of round 3 remain."""
     if not dist.is_initialized() or dist.get_backend() != 'nccl':
         return
     import time
     torch.cuda.synchronize()
-    time.sleep(float(os.environ.get('CAT_DP_CAPTURE_SETTLE_S', '1.0')) if seconds is None else seconds)
+    if seconds is not None:
+        time.sleep(seconds)
+        return
+    deadline = time.monotonic() + float(os.environ.get('CAT_DP_CAPTURE_SETTLE_MAX_S', '30'))
+    state = _watchdog_retired_all()
+    while state is False and time.monotonic() < deadline:
+        time.sleep(0.02)
+        state = _watchdog_retired_all()
+    if state is None:      # no status from this build: a few polling periods
+        time.sleep(float(os.environ.get('CAT_DP_CAPTURE_SETTLE_S', '1.0')))
+    elif state is False:      # never observed; proceed as round 3 did (the captures run with capture_error_mode='thread_local')
+        import warnings
+        warnings.warn('settle_collectives: the RCCL watchdog still reports unfinished collectives after a device synchronize')
 
 
 def shard_batch(batch, rank, world_size):

@@ -391,6 +391,71 @@ int cat_tstage1_dgrad_supported(int w5, int w3, int w1);
 int cat_tstage1_dgrad(const cat_tstage1_t* g, const float* dy, const float* const* packs, float* const* dxs, const int* dxcs,
                       cat_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Quad-granule LDS-tile convolution (csrc/conv_q.hip, round 4): the same K-segment model as cat_tconv_fwd on v_mfma_f32_4x4x1_16B_f32 --
+ * N granule 4 output channels, K granule 1 -- with a source stride and sub-pixel output classes, for the generator's ragged edge layers
+ * (models/modules/inception_architecture/inception_generator.py:37-56: ReflectionPad2d(3) + Conv2d 7x7 (3 -> ngf), two Conv2d 3x3 stride 2;
+ * :118-132: two ConvTranspose2d 3x3 stride 2 padding 1 output_padding 1, ReflectionPad2d(3) + Conv2d 7x7 (ngf -> 3) + Tanh) and any
+ * stride-1 "same" convolution of a pruned student (inception_modules.py:135-147):
+ *   out[n][cy*OS+py][cx*OS+px][co] = act(bias[co] + sum_s sum_(i<kh_s, j<kw_s) sum_c f_s(src_s[n][cy*S+oy_s+i][cx*S+ox_s+j][c]) * W_s(i*kw_s+j, c, co))
+ * over the output LATTICE (cy < Ho, cx < Wo).  ncls = 1: OS = 1, the nseg segments are summed.  ncls = 4: OS = 2, seg[2*py+px] is the ONE
+ * segment of sub-pixel class (py, px) -- nn.ConvTranspose2d(k3, s2, p1, op1) as four dense correlations of the coarse input grid with
+ * 1 / 2 / 2 / 4 taps.  f_s: optional per-channel affine + activation applied while staging (the normalise + ReLU of the train-mode norm
+ * layer in front, inception_generator.py:39-41).  stats: per-tile statistics of the pre-activation output for the norm layer behind
+ * (layout as cat_tconv_fwd `stats` with the plan's tile height; entry = (image * tiles + tile) * ncls + class; merged by
+ * cat_tnorm_finalize2).  Filters and the per-step LDS offsets come from a packed stream (cat_qconv_pack). */
+#define CAT_QCONV_MAXSEG 8
+typedef struct {
+  const float* src;    /* [N][H][W][xcs] at the segment's first channel */
+  const float* scale;  /* optional [c4] staging affine (per image if sstride != 0), NULL = none */
+  const float* shift;
+  int sstride;
+  int xcs, c4, cin;    /* pixel stride, channels rounded up to 4 (padding channels must read as 0 after f_s), valid channels */
+  int kh, kw;          /* tap rectangle */
+  int oy, ox;          /* tap (i, j) of lattice pixel (cy, cx) reads source pixel (cy*S + oy + i, cx*S + ox + j); -pad for a padded conv */
+  int act;             /* CAT_ACT_NONE / RELU / LRELU applied while staging */
+  float slope;
+  int reflect;         /* source pixels outside the plane: 1 = mirrored (nn.ReflectionPad2d), 0 = zero */
+  int pack_off;        /* unused (the stream is laid out in program order by cat_qconv_pack) */
+} cat_qseg_t;
+typedef struct {
+  const float* res;    /* optional residual added after the epilogue activation (ncls = 1 only) */
+  float* stats;        /* optional per-tile statistics (see above); requires act = NONE, res = NULL */
+  int rcs, scs;
+  int N, H, W;         /* source planes (all segments) */
+  int Ho, Wo;          /* output lattice; the output plane is (Ho*OS) x (Wo*OS) */
+  int S, OS, ncls;     /* source stride 1 | 2; output stride / classes: (1, 1) or (2, 4) */
+  int Nn, ycs, ycw;    /* output channels, pixel stride, channels [Nn, ycw) are written as 0 (ycw multiple of 4) */
+  int nvalid;          /* FLOP accounting only; 0 = Nn */
+  int act;             /* epilogue activation (any CAT_ACT_*) */
+  float slope;
+  int nseg;
+  cat_qseg_t seg[CAT_QCONV_MAXSEG];
+} cat_qconv_t;
+typedef struct {
+  int cs, nq, nsplit;  /* channels per staged chunk, output-channel quads per wave, N splits (waves x grid) */
+  int th, tw;          /* output-lattice tile of one workgroup = one statistics entry per class */
+  int tiles;           /* statistics entries per image (tiles x ncls) */
+  int64_t pack_floats; /* floats of the launch's packed stream: [LDS offset table of every step][filters of every step], all segments */
+} cat_qplan_t;
+int cat_qconv_plan(const cat_qconv_t* g, cat_qplan_t* plan);
+/* fewest 16 x 16 lattice tiles for which narrow outputs (<= 8 quads) take the 16 x 16 tiling (default 1024); v < 0 only queries.  Returns the
+ * previous value.  Streams packed before a change stay valid only with the value they were packed under (tests lower it to run both tilings). */
+int cat_qconv_min_tiles16(int v);
+/* Write segment `seg`'s part of the packed stream `dst` (cat_qplan_t.pack_floats floats, zero-initialised once by the caller): its rows of the
+ * offset table and its filters, W(t, c, co) = w[co*s_co + tapsrc[t]*s_tap + c*s_ci] for co < Nn_w (tapsrc NULL = identity).  The geometry must be
+ * the one the stream is launched with (pointers inside g are not read).
+ *   nn.Conv2d weight [Nn][kh*kw][wcs]:                 s_co = kh*kw*wcs, s_tap = wcs, s_ci = 1
+ *   nn.ConvTranspose2d weight [Cin][3*3][wcs >= Nn]:   s_co = 1, s_tap = wcs, s_ci = 9*wcs, tapsrc = the class's (ky, kx) per tap */
+int cat_qconv_pack(const cat_qconv_t* g, int seg, const float* w, float* dst, int Nn_w, const int* tapsrc, int s_co, int s_tap, int s_ci,
+                   cat_stream_t stream);
+int cat_qconv_fwd(const cat_qconv_t* g, const float* pack, const float* bias, float* y, cat_stream_t stream);
+/* cat_tnorm_finalize for a statistics table of th x tw lattice tiles with ncls entries per tile (cat_qconv_fwd); Ho x Wo = the LATTICE, the
+ * norm's pixel count per image is Ho * Wo * ncls.  (cat_tnorm_finalize = th 8, tw 16, ncls 1.) */
+int cat_tnorm_finalize2(const float* part, int scs, int G, int N, int Ho, int Wo, int th, int tw, int ncls, const float* gamma,
+                        const float* beta, int nslices, const cat_nslice_t* slices, float eps, float momentum, float* scale, float* shift,
+                        float* mean, float* rstd, int mstride, cat_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
