@@ -7,6 +7,8 @@ Fusion happens at call time, not by rewriting the module tree, so `shrink_model`
   Conv / Norm      -> accept `fuse_act=` from `FusedSequential`, the activation module that follows is then called
                       with `applied=True` (identity) so its hooks (e.g. 'down_sampling.9') still fire.
 """
+import os
+
 import torch
 from torch import nn
 
@@ -85,7 +87,7 @@ class ReflectionPad2d(nn.ReflectionPad2d):
             raise NotImplementedError('only symmetric reflection padding is supported')
         if isinstance(x, Padded):
             raise NotImplementedError('stacked paddings')
-        return Padded(x, p, L.PAD_REFLECT) if p > 0 else x
+        return Padded(x, p, L.PAD_REFLECT) if p > 0 else x      # x may carry a pending norm (ops.Normed): FusedSequential resolves it
 
 
 class ReplicationPad2d(nn.ReplicationPad2d):
@@ -240,7 +242,9 @@ class BatchNorm2d(_NormMixin, nn.BatchNorm2d):
 
 
 class InstanceNorm2d(_NormMixin, nn.InstanceNorm2d):
-    def forward(self, x, fuse_act=None):
+    def forward(self, x, fuse_act=None, applied=False):
+        if applied:      # computed by the producing conv's statistics epilogue; called only so that forward hooks fire
+            return x
         if self.track_running_stats:
             raise NotImplementedError('InstanceNorm2d(track_running_stats=True) is not used by the distillation scripts')
         return self._run(x, L.NORM_INSTANCE, True, fuse_act)
@@ -261,6 +265,21 @@ class FusedSequential(nn.Sequential):
         while i < n:
             m = mods[i]
             nxt = mods[i + 1] if i + 1 < n else None
+            if isinstance(_inner(x), ops.Normed) and not (isinstance(m, ReflectionPad2d) or _edge_conv(m, nxt, x)):
+                x = _materialized(x)      # nobody but a quad-granule conv consumes a pending norm
+            if _edge_conv(m, nxt, x):
+                # narrow conv -> train-mode norm -> activation of the generator's edge (inception_generator.py:37-56): the conv runs on the
+                # quad-granule kernel with the norm's statistics in its epilogue; in a no-grad forward the normalised tensor is not even
+                # written when the next layer can apply scale / shift while staging
+                act = mods[i + 2] if i + 2 < n and isinstance(mods[i + 2], _ACTS) else None
+                lazy = not torch.is_grad_enabled() and not _hooked(nxt, act) and i + (3 if act is not None else 2) < n
+                x = _conv_norm_q(m, nxt, act, x, lazy)
+                x = nxt(x, applied=True)
+                i += 2
+                if act is not None:
+                    x = act(x, applied=True)
+                    i += 1
+                continue
             if isinstance(m, (Conv2d, ConvTranspose2d)) and _bn_folds(nxt):
                 # frozen network in eval mode: conv + BatchNorm(running stats) [+ activation] = ONE conv kernel
                 act = mods[i + 2] if i + 2 < n and isinstance(mods[i + 2], _ACTS) else None
@@ -287,9 +306,97 @@ class FusedSequential(nn.Sequential):
             else:
                 x = m(x)
                 i += 1
+        x = _materialized(x)
         if fuse_act is not None:         # nothing could absorb it
             x = fuse_act(x)
         return x
+
+
+# ---------------------------------------------------------------------------------------------- the generator's edge on the quad-granule kernel
+_QCONV = os.environ.get('CAT_QCONV', '1') != '0'      # A/B switch
+_QCONV_MAX_C = int(os.environ.get('CAT_QCONV_MAX_C', '48'))
+
+
+def _inner(x):
+    return x.x if isinstance(x, Padded) else x
+
+
+def _materialized(x):
+    if isinstance(x, Padded):
+        return Padded(_materialized(x.x), x.pad, x.mode) if isinstance(x.x, ops.Normed) else x
+    return x.materialize() if isinstance(x, ops.Normed) else x
+
+
+def _hooked(*mods):
+    return any(m is not None and (m._forward_hooks or m._forward_pre_hooks) for m in mods)
+
+
+def _edge_conv(m, nxt, x):
+    """conv `m` followed by norm `nxt` takes the quad-granule path (csrc/conv_q.hip: cat_qconv_fwd with statistics): dense Conv2d with few
+    channels on both sides on a large plane -- the image stem and the first stride-2 conv of a pruned student (3 -> 25 7x7, 25 -> 40 3x3 / 2:
+    measured 175 + 105 us against 223 + 108 us for the im2col kernels + 30 us of separate statistics passes, profiles/r04_qconv_layers.txt)"""
+    if not _QCONV or not isinstance(m, Conv2d) or not isinstance(nxt, _NORMS) or isinstance(nxt, SynchronizedBatchNorm2d):
+        return False
+    if m.groups != 1 or 'weight_orig' in m._parameters or m.dilation != (1, 1) or m.padding_mode != 'zeros' or m.stride[0] != m.stride[1]:
+        return False
+    if isinstance(nxt, BatchNorm2d) and not (nxt.training or not nxt.track_running_stats):
+        return False      # running statistics: the folding path
+    if isinstance(nxt, BatchNorm2d) and nxt.training and nxt.track_running_stats and nxt.momentum is None:
+        return False
+    if isinstance(nxt, InstanceNorm2d) and nxt.track_running_stats:
+        return False
+    inner = _inner(x)
+    t = inner.z if isinstance(inner, ops.Normed) else inner
+    if not torch.is_tensor(t) or not t.is_cuda or t.dim() != 4:
+        return False
+    pad = x.pad if isinstance(x, Padded) else m.padding[0]
+    if isinstance(x, Padded) and (m.padding[0] != 0 or x.mode not in (L.PAD_ZERO, L.PAD_REFLECT)):
+        return False
+    from . import qconv
+    if not qconv.Layer.supported('conv', m.weight, m.stride[0], pad):
+        return False
+    n, c, h, w = t.shape
+    k, st = m.kernel_size[0], m.stride[0]
+    if max(m.in_channels, m.out_channels) > _QCONV_MAX_C or c != m.in_channels:
+        return False
+    if pad >= min(h, w):
+        return False
+    ho, wo = (h + 2 * pad - k) // st + 1, (w + 2 * pad - k) // st + 1
+    return n * ((ho + 7) // 8) * ((wo + 15) // 16) >= ops._TCONV_MIN_TILES
+
+
+def _conv_norm_q(conv, norm, act_mod, x, lazy):
+    from . import qconv
+    pad, mode = conv.padding[0], L.PAD_ZERO
+    if isinstance(x, Padded):
+        x, pad, mode = x.x, x.pad, x.mode
+    _to_channels_last_(conv)
+    layer = getattr(conv, '_cat_q', None)
+    if layer is None or layer.weight is not conv.weight or layer.pad != pad or layer.reflect != (mode == L.PAD_REFLECT):
+        layer = conv._cat_q = qconv.Layer('conv', conv.weight, stride=conv.stride[0], pad=pad, reflect=mode == L.PAD_REFLECT)
+    act, slope = _act_code(act_mod)
+    inst = isinstance(norm, InstanceNorm2d)
+    nmode = L.NORM_INSTANCE if inst else L.NORM_BATCH
+    track = (not inst) and norm.training and norm.track_running_stats
+    rm, rv, nbt = (norm.running_mean, norm.running_var, norm.num_batches_tracked) if track else (None, None, None)
+    eps, mom = float(norm.eps), float(norm.momentum if norm.momentum is not None else 0.0)
+    q = {'layer': layer, 'stats': True}
+    if isinstance(x, ops.Normed) or lazy:      # no-grad forward
+        pre = x.pre() if isinstance(x, ops.Normed) else None
+        src = x.z if isinstance(x, ops.Normed) else ops.conform(x)
+        n, c, h, w = src.shape
+        cout, ho, wo = layer.out_shape(src)
+        z = ops.empty_act(n, cout, ho, wo, src.device)
+        ops.run_qconv(q, src, conv.bias, z, pre=pre)
+        tiles = dict(table=q['table'], plan=q['plan'], scs=q['scs'], lat=(ho, wo), ncls=1)
+        groups = n if inst else 1
+        scale, shift = ops.norm_from_tiles(tiles, n, cout, groups, norm.weight, norm.bias, rm, rv, nbt, eps, mom)
+        out = ops.Normed(z, scale, shift, groups, act, slope)
+        return out if lazy else out.materialize()
+    z = ops.Conv2dFn.apply(x, conv.weight, conv.bias, conv.stride[0], pad, mode, L.ACT_NONE, 0.0, q)
+    tiles = dict(table=q['table'], plan=q['plan'], scs=q['scs'], lat=(z.shape[2], z.shape[3]), ncls=1)
+    return ops.NormActFn.apply(z, norm.weight, norm.bias, rm, rv, nmode, eps, mom, act, slope, nbt, tiles)
+
 
 # ---------------------------------------------------------------------------------------------- SPADE / GauGAN layers
 class SynchronizedBatchNorm2d(BatchNorm2d):

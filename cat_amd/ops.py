@@ -400,7 +400,9 @@ class Conv2dFn(torch.autograd.Function):
     """nn.Conv2d (+ preceding ReflectionPad2d, + following pointwise activation)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, pad_mode, act, slope):
+    def forward(ctx, x, weight, bias, stride, pad, pad_mode, act, slope, q=None):
+        """q (optional): {'layer': qconv.Layer, 'stats': bool} -- run the layer on the quad-granule kernel (csrc/conv_q.hip); with 'stats' the
+        per-tile statistics of the output land in q['table'] (+ q['plan']) for the train-mode norm behind (NormActFn `tiles`)."""
         _require_cuda(x)
         x = conform(x)
         wcl, wcs = weight_cl(weight)
@@ -411,7 +413,9 @@ class Conv2dFn(torch.autograd.Function):
         ho = (h + 2 * pad - kh) // stride + 1
         wo = (w + 2 * pad - kw) // stride + 1
         y = empty_act(n, cout, ho, wo, x.device)
-        if tconv_applicable(n, h, w, cout, kh, kw, stride, pad, cin):
+        if q is not None:
+            run_qconv(q, x, bias, y, act, slope)
+        elif tconv_applicable(n, h, w, cout, kh, kw, stride, pad, cin):
             from . import tconv
             pk = packed_filter(weight, wcl, tconv.FWD)
             tconv.run([tconv.Segment(x, kh, pad, pad_mode == L.PAD_REFLECT, 0)], pk, bias, y, cout, n, h, w, ho, wo, act, slope)
@@ -465,7 +469,48 @@ class Conv2dFn(torch.autograd.Function):
             ws = workspace(L.query('cat_channel_sum_ws_bytes', m, act_cs(dy)), x.device)
             db = _write_param_grad(ctx.bias, lambda dst, acc: L.call('cat_channel_sum', _p(dy), m, cout, act_cs(dy), _p(dst), acc,
                                                                      _p(ws), st))
-        return dx, dw, db, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None
+
+
+def run_qconv(q, x, bias, y, act=L.ACT_NONE, slope=0.0, pre=None):
+    """One launch of a qconv.Layer; q['stats'] -> allocate the tile-statistics table and leave (table, plan) in q."""
+    layer = q['layer']
+    table, scs = None, 0
+    if q.get('stats'):
+        n = x.shape[0]
+        scs = act_cs(y)
+        plan0 = layer.plan_for(x)
+        table = torch.empty(n * plan0.tiles * 2 * scs, device=x.device, dtype=torch.float32)
+    plan = layer.run(x, bias, y, act=act, slope=slope, pre=pre, stats=table, scs=scs)
+    q['table'], q['plan'], q['scs'] = table, plan, scs
+    return plan
+
+
+class Normed:
+    """A pre-norm conv output with its pending train-mode norm + activation (scale / shift rows from cat_tnorm_finalize2): produced only in
+    no-grad forwards, consumed by a quad-granule conv that applies them while staging (no normalised copy is written), or materialised."""
+    __slots__ = ('z', 'scale', 'shift', 'groups', 'act', 'slope')
+
+    def __init__(self, z, scale, shift, groups, act, slope):
+        self.z, self.scale, self.shift, self.groups, self.act, self.slope = z, scale, shift, groups, act, slope
+
+    @property
+    def shape(self):
+        return self.z.shape
+
+    def pre(self):
+        """(scale, shift, sstride, act, slope) for qconv.Layer.run"""
+        return self.scale, self.shift, (self.scale.shape[1] if self.groups > 1 else 0), self.act, self.slope
+
+    def materialize(self):
+        z = self.z
+        n, c, h, w = z.shape
+        cs = act_cs(z)
+        y = empty_act(n, c, h, w, z.device, cs)
+        g = self.groups
+        L.call('cat_affine_res_fwd', _p(z), cs, _p(self.scale), _p(self.shift), self.scale.shape[1] if g > 1 else 0, None, 0, _p(y), cs, g,
+               (n // g) * h * w, cs, self.act, self.slope, _stream())
+        return y
 
 
 def _grad_wcs(t):
@@ -583,7 +628,9 @@ class NormActFn(torch.autograd.Function):
     """InstanceNorm2d / BatchNorm2d with batch statistics, fused with the activation behind it."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, mode, eps, momentum, act, slope, num_batches=None):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, mode, eps, momentum, act, slope, num_batches=None, tiles=None):
+        """tiles (optional): the producing conv's per-tile statistics {'table', 'plan', 'scs', 'lat': (h, w), 'ncls'} (cat_qconv_fwd `stats`):
+        the statistics pass is skipped -- cat_tnorm_finalize2 + one apply pass."""
         _require_cuda(x)
         x = conform(x)
         n, c, h, w = x.shape
@@ -593,9 +640,14 @@ class NormActFn(torch.autograd.Function):
         groups = n if mode == L.NORM_INSTANCE else 1
         mean = torch.empty((groups, c), device=x.device, dtype=torch.float32)
         rstd = torch.empty((groups, c), device=x.device, dtype=torch.float32)
-        ws = workspace(L.query('cat_norm_ws_bytes', C.byref(g)), x.device)
-        L.call('cat_norm_fwd', C.byref(g), _p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), _p(running_mean), _p(running_var),
-               _p(num_batches), _p(ws), _stream())
+        if tiles is not None:
+            scale, shift = norm_from_tiles(tiles, n, c, groups, gamma, beta, running_mean, running_var, num_batches, eps, momentum, mean, rstd)
+            L.call('cat_affine_res_fwd', _p(x), cs, _p(scale), _p(shift), scale.shape[1] if groups > 1 else 0, None, 0, _p(y), cs, groups,
+                   (n // groups) * h * w, cs, act, slope, _stream())
+        else:
+            ws = workspace(L.query('cat_norm_ws_bytes', C.byref(g)), x.device)
+            L.call('cat_norm_fwd', C.byref(g), _p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), _p(running_mean), _p(running_var),
+                   _p(num_batches), _p(ws), _stream())
         ctx.geom = (n, h * w, c, cs, mode, eps, momentum, act, slope)
         ctx.gamma, ctx.beta = gamma, beta
         ctx.save_for_backward(x, mean, rstd, gamma, beta)
@@ -631,7 +683,29 @@ class NormActFn(torch.autograd.Function):
             dbeta = torch.empty_like(beta) if need_b else None
             L.call('cat_norm_bwd', C.byref(g), _p(x), _p(dy), _p(gamma), _p(beta), _p(mean), _p(rstd), _p(dx), _p(dgamma), _p(dbeta), 0,
                    _p(ws), st)
-        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None, None
+
+
+def norm_from_tiles(tiles, n, c, groups, gamma, beta, running_mean, running_var, num_batches, eps, momentum, mean=None, rstd=None):
+    """cat_tnorm_finalize2 over a conv's tile-statistics table: scale / shift rows [groups][scs] of the train-mode norm (+ its running
+    statistics, torch semantics) and, if given, mean / rstd [groups][c] for cat_norm_bwd."""
+    table, plan, scs = tiles['table'], tiles['plan'], tiles['scs']
+    lat_h, lat_w = tiles['lat']
+    dev = table.device
+    scale = torch.empty((groups, scs), device=dev, dtype=torch.float32)
+    shift = torch.empty((groups, scs), device=dev, dtype=torch.float32)
+    if mean is None:
+        mean = torch.empty((groups, c), device=dev, dtype=torch.float32)
+        rstd = torch.empty((groups, c), device=dev, dtype=torch.float32)
+    sl = (L.NSlice * 1)()
+    sl[0].c0, sl[0].c = 0, c
+    if running_mean is not None:
+        sl[0].running_mean, sl[0].running_var = running_mean.data_ptr(), running_var.data_ptr()
+        if num_batches is not None:
+            sl[0].num_batches = num_batches.data_ptr()
+    L.call('cat_tnorm_finalize2', _p(table), scs, groups, n, lat_h, lat_w, plan.th, plan.tw, tiles.get('ncls', 1), _p(gamma), _p(beta), 1, sl,
+           eps, momentum, _p(scale), _p(shift), _p(mean), _p(rstd), c, _stream())
+    return scale, shift
 
 
 def affine_act(x, scale, shift, act, slope):

@@ -120,6 +120,19 @@ class Layer:
             return [Seg(x, k, k, -self.pad, -self.pad, reflect=self.reflect, **kw)]
         return [Seg(x, 1 + (c >> 1), 1 + (c & 1), 0, 0, **kw) for c in range(4)]
 
+    def plan_for(self, x):
+        """The launch plan for an input of x's shape (tile geometry / entries of the statistics table) without launching."""
+        n, c, h, w = x.shape
+        key = (n, h, w, c)
+        plan = self._plans.get(key)
+        if plan is None:
+            nn, ho, wo = self.out_shape(x)
+            ct = self.kind == 'convt'
+            g = geometry(self._segments(x, None), n, h, w, h if ct else ho, w if ct else wo, nn, cs4(nn), stride=1 if ct else self.stride,
+                         ncls=4 if ct else 1)
+            plan = self._plans[key] = plan_of(g)
+        return plan
+
     def run(self, x, bias, y, act=L.ACT_NONE, slope=0.0, pre=None, stats=None, scs=0):
         """Returns the plan (tile geometry of the statistics table).  y: NHWC output activation."""
         from . import optim

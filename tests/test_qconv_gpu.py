@@ -238,3 +238,74 @@ def test_qconv_k_segments_sum(dev):
     qconv.launch(g, buf, None, y.data_ptr())
     torch.cuda.synchronize()
     assert rel(y, ref) < TOL
+
+
+@pytest.mark.parametrize('norm', ['batch', 'instance'])
+def test_generator_edge_through_fused_sequential(dev, norm):
+    """ReflectionPad2d(3) . Conv 7x7 . norm . ReLU . Conv 3x3 / 2 . norm . ReLU . Conv 3x3 / 2 (wide) . norm . ReLU -- the down-sampling
+    head of InceptionGenerator (reference inception_generator.py:37-56) with a pruned student's widths -- through cat_amd.nn.FusedSequential:
+    the first two convs take the quad-granule kernel with statistics in the epilogue.  No-grad forward (pending norms applied in the next
+    conv's staging), grad-mode forward, every gradient and the running statistics against stock torch on the host."""
+    from torch import nn as tnn
+    from cat_amd import nn as cnn, ops, qconv
+    old = ops.set_tconv_min_tiles(1)
+    try:
+        torch.manual_seed(5)
+        inst = norm == 'instance'
+        widths = (3, 22, 37, 77)
+
+        def build(mod):
+            Norm = (lambda c: mod.InstanceNorm2d(c, affine=True)) if inst else (lambda c: mod.BatchNorm2d(c))
+            layers = [mod.ReflectionPad2d(3), mod.Conv2d(widths[0], widths[1], 7, padding=0, bias=inst), Norm(widths[1]), mod.ReLU(True)]
+            for a, b in zip(widths[1:-1], widths[2:]):
+                layers += [mod.Conv2d(a, b, 3, stride=2, padding=1, bias=inst), Norm(b), mod.ReLU(True)]
+            return layers
+
+        ref = tnn.Sequential(*build(tnn))
+        for p_ in ref.parameters():
+            p_.data.normal_(0, 0.3)
+        net = cnn.FusedSequential(*build(cnn)).to(dev)
+        net.load_state_dict(ref.state_dict())
+        ref.train(), net.train()
+        x = _gen(2, 3, 40, 48, seed=21)
+        xd = ops.to_nhwc(x.to(dev))
+        calls = {'n': 0}
+        orig = qconv.Layer.run
+
+        def counting(self, *a, **k):
+            calls['n'] += 1
+            return orig(self, *a, **k)
+        qconv.Layer.run = counting
+        try:
+            with torch.no_grad():
+                y0 = net(xd)
+            assert calls['n'] == 2, 'the stem and the first stride-2 conv take the quad-granule kernel'
+            xg = xd.detach().requires_grad_(True)
+            y1 = net(xg)
+            assert calls['n'] == 4
+        finally:
+            qconv.Layer.run = orig
+        xr = x.clone().requires_grad_(True)
+        ref2 = tnn.Sequential(*build(tnn))
+        ref2.load_state_dict(ref.state_dict())
+        ref2.train()
+        with torch.no_grad():
+            yr0 = ref2(x)                      # first training-mode forward (running statistics move once, like net's no-grad pass)
+        yr = ref2(xr)
+        assert rel(y0, yr0) < TOL and rel(y1, yr) < TOL
+        gy = _gen(*yr.shape, seed=22)
+        yr.backward(gy)
+        y1.backward(ops.to_nhwc(gy.to(dev)))
+        torch.cuda.synchronize()
+        assert rel(xg.grad, xr.grad) < 5e-4
+        gmax = max(float(pr.grad.abs().max()) for pr in ref2.parameters())
+        for (k, pg), (_, pr) in zip(net.named_parameters(), ref2.named_parameters()):
+            if float(pr.grad.abs().max()) < 1e-4 * gmax:      # a conv bias in front of a norm: the exact gradient is 0, both sides hold round-off
+                assert float((pg.grad.cpu() - pr.grad).abs().max()) < 1e-3 * gmax, k
+            else:
+                assert rel(pg.grad, pr.grad) < 5e-4, k
+        if not inst:
+            for (k, bg), (_, br) in zip(net.named_buffers(), ref2.named_buffers()):
+                assert rel(bg.float(), br.float()) < TOL, k
+    finally:
+        ops.set_tconv_min_tiles(old)
