@@ -280,7 +280,7 @@ def test_spade_step_at_512x256_matches_oracle(capsys):
         TS.check_grads(m.netD.named_parameters(), st.grads_D, st64.grads_D, label='[SPADE discriminator gradients @512x256, batch %d]' % nb)
     assert ops.STATS['conform_copies'] == 0
     for k, v in report.items():
-        assert v < 2e-3, (k, v)
+        assert v < 1e-3, (k, v)      # north_star's tolerance (observed <= 9e-5)
     # updated weights (TTUR Adam, beta1 = 0: the first step is -lr * sign(grad)): the bulk of every tensor agrees to round-off, nothing moves
     # further than a flipped first step
     worst_q = 0.0

@@ -269,7 +269,7 @@ def check_grads(named_params, ref_grads, ref_grads64=None, label='grad parity'):
         gpu64 = GPU (fp32 kernels) vs the fp64 gradient          ref64 = the oracle's own fp32 gradient vs the fp64 gradient
     Two independent fp32 evaluations cannot be compared tensor by tensor (each lands on its own side of its own borderline units), so
     the bar is on the distributions: median, 90 % quantile and worst tensor of gpu64 must not exceed 2x the oracle's own fp32 figure
-    (+ 1e-3).  tools/oracle_fp64_calibration.py prints the ref64 column alone (CPU only).  Without `ref_grads64` (small fixtures): every
+    (+ 1e-3), plus a per-tensor net: gpu64 <= max(10 x ref64, 5e-3).  tools/oracle_fp64_calibration.py prints the ref64 column alone (CPU only).  Without `ref_grads64` (small fixtures): every
     tensor within 5e-3 of the network's largest gradient entry and the median tensor within 1e-3 of its own scale."""
     gmax = max(float(v.abs().max()) for v in ref_grads.values())
     rows = []
@@ -306,6 +306,13 @@ def check_grads(named_params, ref_grads, ref_grads64=None, label='grad parity'):
         print('    %-44s gpu64 %.2e   ref64 %.2e' % (r['k'], r['gpu64'], r['ref64']))
     for name, (a, b) in stats.items():
         assert a <= 2.0 * b + 1e-3, (label, name, a, b)
+    # per-tensor safety net (round 4): the distribution bars above would let ONE tensor be wrong by tens of percent where the oracle's own
+    # worst tensor is that far from the fp64 gradient.  A tensor the fp32 oracle resolves well must be resolved by the kernels too:
+    # gpu64 <= max(10 x ref64, 5e-3).  Tensors that only pass through the 5e-3 floor are counted and printed.
+    floor = [r for r in rows if r['gpu64'] > 10.0 * r['ref64']]
+    bad = [r for r in floor if r['gpu64'] > 5e-3]
+    print('%s per-tensor net gpu64 <= max(10 x ref64, 5e-3): %d of %d tensors need the 5e-3 floor, %d fail' % (label, len(floor), len(rows), len(bad)))
+    assert not bad, (label, [(r['k'], r['gpu64'], r['ref64']) for r in bad[:5]])
 
 
 @pytest.mark.parametrize('which', ['student_train', 'teacher_eval'])

@@ -343,25 +343,34 @@ def eval_utils_golden():
     print('eval_utils.npz', {k: v.shape for k, v in out.items()})
 
 
-if __name__ == '__main__':
-    if os.environ.get('GOLDEN_ONLY') == 'small':
-        small_ops()
-        sys.exit(0)
-    if os.environ.get('GOLDEN_ONLY') == 'eval':
-        eval_utils_golden()
-        sys.exit(0)
-    if os.environ.get('GOLDEN_ONLY') == 'transfer':
-        weight_transfer_golden()
-        sys.exit(0)
-    if os.environ.get('GOLDEN_ONLY') == 'train':
-        teacher_training_steps()
-        sys.exit(0)
-    if os.environ.get('GOLDEN_ONLY') == 'mse':
-        # distill_G_loss_type='mse' (the flag's default, inception_distiller.py:113-132): MSE(netA(Sact), Tact) through the 1x1 adaptors
-        run_config('mse', 'instance', False, 2.6e9, 'unaligned', 'lsgan', 64, 5.0, 1.0, 64, 2, distill='mse', keep=('step',))
-        sys.exit(0)
+def mse_step():
+    # distill_G_loss_type='mse' (the flag's default, inception_distiller.py:113-132): MSE(netA(Sact), Tact) through the 1x1 adaptors
+    run_config('mse', 'instance', False, 2.6e9, 'unaligned', 'lsgan', 64, 5.0, 1.0, 64, 2, distill='mse', keep=('step',))
+
+
+def main_configs():
     small_ops()
     # C3-like: CycleGAN student (InstanceNorm affine, lsgan, unaligned, ndf 64, lambda_recon 5), SURVEY §8d
     run_config('in', 'instance', False, 2.6e9, 'unaligned', 'lsgan', 64, 5.0, 1.0, 64, 2)
     # C2-like: pix2pix student (BatchNorm + running stats, hinge, aligned, ndf 128, lambda_recon 100, lambda_distill 1.3)
     run_config('bn', 'batch', True, 4.6e9, 'aligned', 'hinge', 128, 100.0, 1.3, 64, 2)
+
+
+PARTS = {'small': small_ops, 'eval': eval_utils_golden, 'transfer': weight_transfer_golden, 'train': teacher_training_steps, 'mse': mse_step,
+         'main': main_configs}
+
+
+if __name__ == '__main__':
+    # `python tools/make_golden.py` regenerates EVERY inception-path fixture (round 4; the four extra parts used to need GOLDEN_ONLY=...
+    # invocations).  Each part runs in its own interpreter: the reference's modules keep global state (option singletons, the RNG streams
+    # the fixtures were recorded under), so a part must see a fresh import.  GOLDEN_ONLY=<part> still runs a single part.
+    only = os.environ.get('GOLDEN_ONLY')
+    if only:
+        PARTS[only]()
+        sys.exit(0)
+    import subprocess
+    for part in ('main', 'mse', 'eval', 'transfer', 'train'):
+        print('== make_golden part:', part, flush=True)
+        subprocess.run([sys.executable, os.path.abspath(__file__)], env=dict(os.environ, GOLDEN_ONLY=part), check=True)
+    print('== tools/make_golden_spade.py', flush=True)
+    subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'make_golden_spade.py')], check=True)
