@@ -105,6 +105,8 @@ SIGNATURES = {
     'cat_tstage1_dgrad': (c_i, [C.POINTER(Stage1Geom), c_p, c_p, c_p, c_p, c_p]),
     'cat_tnorm_finalize': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_i, c_p]),
     'cat_tnorm_finalize2': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_i, c_p]),
+    'cat_tnorm_sums': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
+    'cat_tnorm_finalize_sums': (c_i, [c_p, c_d, c_i, c_p, c_p, c_i, c_p, c_f, c_f, c_i, c_p, c_p, c_p, c_p, c_p]),
     'cat_qconv_min_tiles16': (c_i, [c_i]),
     'cat_qconv_plan': (c_i, [C.POINTER(QConv), C.POINTER(QPlan)]),
     'cat_qconv_pack': (c_i, [C.POINTER(QConv), c_i, c_p, c_p, c_i, C.POINTER(c_i), c_i, c_i, c_i, c_p]),

@@ -101,6 +101,66 @@ __global__ __launch_bounds__(256) void tnorm_finalize_kernel(const float* __rest
   shift[idx] = be - mean * ga * rstd;
 }
 
+// SynchronizedBatchNorm over ranks for the fused units (models/modules/sync_batchnorm/batchnorm.py:103-140): the tile table of THIS rank is
+// folded to [sum x | sum x^2] per channel (sum x^2 of a tile = M2 + sum^2 / n), the host all-reduces the 2 * scs floats ONCE per stage, and
+// tnorm_finalize_sums_kernel applies the reference's multi-replica formula (mean = sum / size, sumvar = ssum - sum * mean,
+// inv_std = clamp(sumvar / size, eps)^-1/2, running_var from the unbiased sumvar / (size - 1)) to every norm module of the stage at once.
+// grid cdiv(scs, 4), one wave per channel
+__global__ __launch_bounds__(256) void tnorm_sums_kernel(const float* __restrict__ part, int scs, int ntile, int per_img, int tiles_x, int Ho, int Wo,
+                                                         int th, int tw, int ncls, float* __restrict__ sums) {
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (c >= scs) return;
+  float s = 0.f, q = 0.f;
+  for (int t = lane; t < ntile; t += 64) {
+    const int ti = (t % per_img) / ncls;
+    const int ty = ti / tiles_x, tx = ti - ty * tiles_x;
+    const float n = (float)(min(th, Ho - ty * th) * min(tw, Wo - tx * tw));
+    const float st = part[(int64_t)t * 2 * scs + c], m2 = part[(int64_t)t * 2 * scs + scs + c];
+    s += st;
+    q += m2 + st * st / n;
+  }
+  s = cat::wave_sum(s);
+  q = cat::wave_sum(q);
+  if (lane == 0) {
+    sums[c] = s;
+    sums[scs + c] = q;
+  }
+}
+
+__global__ __launch_bounds__(256) void tnorm_finalize_sums_kernel(const float* __restrict__ sums, float count, int scs, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta, FinArgs fa, float eps, float momentum, int clamp,
+                                                                  float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ a,
+                                                                  float* __restrict__ b) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= scs) return;
+  int sl = -1;
+  for (int k = 0; k < fa.nsl; ++k)
+    if (c >= fa.sl[k].c0 && c < fa.sl[k].c0 + fa.sl[k].c) sl = k;
+  if (sl < 0) {
+    scale[c] = shift[c] = a[c] = b[c] = 0.f;
+    return;
+  }
+  const float sum = sums[c], ssum = sums[scs + c];
+  const float mean = sum / count;
+  float sumvar = ssum - sum * mean;
+  sumvar = sumvar > 0.f ? sumvar : 0.f;
+  const float var = sumvar / count;
+  const float rstd = clamp ? rsqrtf(fmaxf(var, eps)) : rsqrtf(var + eps);
+  const cat_nslice_t& S = fa.sl[sl];
+  const int cl = c - S.c0;
+  if (S.running_mean) {
+    const float unb = count > 1.f ? sumvar / (count - 1.f) : var;
+    S.running_mean[cl] = (1.f - momentum) * S.running_mean[cl] + momentum * mean;
+    S.running_var[cl] = (1.f - momentum) * S.running_var[cl] + momentum * unb;
+    if (S.num_batches && cl == 0) *S.num_batches += 1;
+  }
+  a[c] = rstd;
+  b[c] = -mean * rstd;
+  const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
+  scale[c] = ga * rstd;
+  shift[c] = be - mean * ga * rstd;
+}
+
 // y = act(x * scale[g][c] + shift[g][c]) (+ res): (pixel, quad) walk with 32-bit indices inside a group
 __global__ __launch_bounds__(256) void affine_res_kernel(const float* __restrict__ x, int xcs, const float* __restrict__ scale,
                                                          const float* __restrict__ shift, int sstride, const float* __restrict__ res, int rcs,
@@ -299,6 +359,29 @@ int cat_tnorm_finalize(const float* part, int scs, int G, int N, int Ho, int Wo,
                        const cat_nslice_t* slices, float eps, float momentum, float* scale, float* shift, float* mean, float* rstd,
                        int mstride, cat_stream_t stream) {
   return cat_tnorm_finalize2(part, scs, G, N, Ho, Wo, TH, TW, 1, gamma, beta, nslices, slices, eps, momentum, scale, shift, mean, rstd, mstride, stream);
+}
+
+int cat_tnorm_sums(const float* part, int scs, int N, int Ho, int Wo, int th, int tw, int ncls, float* sums, cat_stream_t stream) {
+  CAT_REQUIRE(part && sums && (scs & 3) == 0 && N > 0 && Ho > 0 && Wo > 0 && th > 0 && tw > 0 && ncls >= 1, "tnorm sums: bad arguments");
+  const int tiles_x = cdiv(Wo, tw), per_img = tiles_x * cdiv(Ho, th) * ncls;
+  tnorm_sums_kernel<<<cdiv(scs, 4), 256, 0, (hipStream_t)stream>>>(part, scs, per_img * N, per_img, tiles_x, Ho, Wo, th, tw, ncls, sums);
+  return cat::check_launch("tnorm_sums");
+}
+
+int cat_tnorm_finalize_sums(const float* sums, double count, int scs, const float* gamma, const float* beta, int nslices,
+                            const cat_nslice_t* slices, float eps, float momentum, int clamp, float* scale, float* shift, float* a, float* b,
+                            cat_stream_t stream) {
+  CAT_REQUIRE(sums && scale && shift && a && b && count > 0 && (scs & 3) == 0, "tnorm finalize sums: bad arguments");
+  CAT_REQUIRE(nslices >= 1 && nslices <= CAT_TNORM_MAXSLICE, "tnorm finalize sums: %d slices", nslices);
+  FinArgs fa{};
+  fa.nsl = nslices;
+  for (int k = 0; k < nslices; ++k) {
+    fa.sl[k] = slices[k];
+    CAT_REQUIRE(slices[k].c0 >= 0 && slices[k].c > 0 && slices[k].c0 + slices[k].c <= scs, "tnorm finalize sums: slice %d outside the table", k);
+  }
+  tnorm_finalize_sums_kernel<<<cdiv(scs, 256), 256, 0, (hipStream_t)stream>>>(sums, (float)count, scs, gamma, beta, fa, eps, momentum, clamp, scale, shift,
+                                                                               a, b);
+  return cat::check_launch("tnorm_finalize_sums");
 }
 
 int cat_affine_res_fwd(const float* x, int xcs, const float* scale, const float* shift, int sstride, const float* res, int rcs, float* y,

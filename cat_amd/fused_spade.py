@@ -34,9 +34,10 @@ _ENABLED = os.environ.get('CAT_FUSED_SPADE', '1') != '0'      # A/B switch; 'tra
 _ONLY = os.environ.get('CAT_FUSED_SPADE', '1') if os.environ.get('CAT_FUSED_SPADE', '1') in ('train', 'frozen') else None
 
 
+_SYNC_FUSED = os.environ.get('CAT_FUSED_SPADE_SYNC', '1') != '0'      # fused units under SynchronizedBatchNorm over several ranks (round 4)
 _S1_DGRAD = os.environ.get('CAT_FUSED_SPADE_S1_DGRAD', '1') != '0'     # A/B switch: the second convs' input gradients as one launch
 _UNITS = os.environ.get('CAT_FUSED_SPADE_UNITS', 'all')      # A/B switch: 'gb' / 'main' = only the gamma|beta nets / only the main units
-STATS = {'train_fwd': 0, 'frozen_fwd': 0, 'bwd': 0}      # calls per form (tests / diagnostics)
+STATS = {'train_fwd': 0, 'frozen_fwd': 0, 'bwd': 0, 'collectives': 0}      # calls per form; statistics exchanges issued (tests / diagnostics)
 
 
 def set_enabled(on):
@@ -76,14 +77,18 @@ def applicable(res_ops, dw_ops, x, training):
         return False
     if _ONLY is not None and _ONLY != ('train' if training else 'frozen'):
         return False
-    if training and ops.bn_sync() is not None:
-        return False
+    if training and ops.bn_sync() is not None and not _SYNC_FUSED:
+        return False      # A/B switch: the per-layer path with one statistics exchange per norm layer
     if not training and torch.is_grad_enabled():
         return False
     if len(res_ops) + len(dw_ops) == 0 or len(res_ops) + len(dw_ops) > L.TCONV_MAXSEG:
         return False
     n, c, h, w = x.shape
-    if not ops.tconv_applicable(n, h, w, 16, 3, 3, 1, 1):
+    # planes too small to fill the chip run faster layer by layer on ONE GPU (split-K im2col kernels: 62.8 vs 60.9 images/s, round 3) -- but
+    # layer by layer every norm is its own statistics exchange over the ranks (18 per unit against 4): under SynchronizedBatchNorm with
+    # N > 1 ranks every unit the kernels can run is fused
+    synced = training and ops.bn_sync() is not None and _SYNC_FUSED
+    if not synced and not ops.tconv_applicable(n, h, w, 16, 3, 3, 1, 1):
         return False
     if c == 1:      # FusedAdam stores [m][1][1][1] weights unpadded (row stride 1): the merged first-conv gradient scatter writes cs4(Cin)-wide rows
         return False
@@ -335,10 +340,24 @@ def _slices(pairs):
 
 
 def _finalize(p, part, scs, n, h, w, gamma, beta, pairs):
+    """(scale | shift), (mean | rstd) of every norm of a stage.  With a SynchronizedBatchNorm reducer installed (N > 1 ranks) the stage's
+    statistics are exchanged ONCE: this rank's tile table -> [sum x | sum x^2] of the whole concatenation -> one all-reduce -> the
+    reference's multi-replica formula (batchnorm.py:103-140: clamp(var, eps), unbiased running_var); the second tensor then holds
+    (a | b) = (inv_std | -mean * inv_std) for the split-phase backward."""
     ss = torch.empty((2, 1, scs), device=part.device, dtype=torch.float32)
     mr = torch.empty((2, 1, scs), device=part.device, dtype=torch.float32)
-    L.call('cat_tnorm_finalize', ops._p(part), scs, 1, n, h, w, ops._p(gamma), ops._p(beta), len(pairs), _slices(pairs), p.eps, p.momentum,
-           ops._p(ss[0]), ops._p(ss[1]), ops._p(mr[0]), ops._p(mr[1]), scs, ops._stream())
+    sync = ops.bn_sync()
+    if sync is None:
+        L.call('cat_tnorm_finalize', ops._p(part), scs, 1, n, h, w, ops._p(gamma), ops._p(beta), len(pairs), _slices(pairs), p.eps, p.momentum,
+               ops._p(ss[0]), ops._p(ss[1]), ops._p(mr[0]), ops._p(mr[1]), scs, ops._stream())
+        return ss, mr
+    sums = torch.empty(2 * scs, device=part.device, dtype=torch.float32)
+    L.call('cat_tnorm_sums', ops._p(part), scs, n, h, w, 8, 16, 1, ops._p(sums), ops._stream())
+    sync.all_reduce_sum_(sums)
+    STATS['collectives'] += 1
+    count = float(n * h * w) * sync.world_size
+    L.call('cat_tnorm_finalize_sums', ops._p(sums), count, scs, ops._p(gamma), ops._p(beta), len(pairs), _slices(pairs), p.eps, p.momentum, 1,
+           ops._p(ss[0]), ops._p(ss[1]), ops._p(mr[0]), ops._p(mr[1]), ops._stream())
     return ss, mr
 
 
@@ -467,9 +486,27 @@ def forward_eval(p, x, addend):
     return y
 
 
-def _norm_bwd(p, n, hw, c, cs, x, dy, gamma, beta, mr, dgamma, dbeta):
-    g = L.NormGeom(n, hw, c, cs, L.NORM_BATCH, p.eps, p.momentum, p.act, p.slope)
+def _norm_bwd(p, n, hw, c, cs, x, dy, gamma, beta, mr, dgamma, dbeta, synced=False):
     dx = torch.empty((n, hw, cs), device=x.device, dtype=torch.float32)
+    if synced:
+        # SynchronizedBatchNorm backward over ranks: local [sum g | sum g * xhat] of the whole stage -> ONE all-reduce -> apply; the parameter
+        # gradients stay local sums (the gradient bucket all-reduce averages them), as in ops.SyncBNFn
+        sync = ops.bn_sync()
+        if sync is None:
+            raise RuntimeError('fused SPADE unit backward: the forward ran under a SynchronizedBatchNorm reducer that is gone')
+        m = n * hw
+        sums = torch.empty(2 * cs, device=x.device, dtype=torch.float32)
+        ws = ops.workspace(L.query('cat_bn_ws_bytes', m, cs), x.device)
+        st = ops._stream()
+        L.call('cat_bn_stats_bwd', ops._p(x), ops._p(dy), ops._p(gamma), ops._p(beta), ops._p(mr[0]), ops._p(mr[1]), m, c, cs, p.act, p.slope,
+               ops._p(sums), ops._p(ws), st)
+        local = sums.clone()
+        sync.all_reduce_sum_(sums)
+        STATS['collectives'] += 1
+        L.call('cat_bn_apply_bwd', ops._p(x), ops._p(dy), ops._p(gamma), ops._p(beta), ops._p(mr[0]), ops._p(mr[1]), ops._p(sums),
+               float(m * sync.world_size), ops._p(local), ops._p(dx), ops._p(dgamma), ops._p(dbeta), 0, m, c, cs, p.act, p.slope, st)
+        return dx
+    g = L.NormGeom(n, hw, c, cs, L.NORM_BATCH, p.eps, p.momentum, p.act, p.slope)
     ws = ops.workspace(L.query('cat_norm_ws_bytes', C.byref(g)), x.device)
     L.call('cat_norm_bwd', C.byref(g), ops._p(x), ops._p(dy), ops._p(gamma), ops._p(beta), ops._p(mr[0]), ops._p(mr[1]), ops._p(dx), ops._p(dgamma),
            ops._p(dbeta), 0, ops._p(ws), ops._stream())
@@ -490,6 +527,7 @@ class _UnitFn(torch.autograd.Function):
         save = {}
         y = forward(plan, x, addend, save)
         ctx.plan = plan
+        ctx.synced = ops.bn_sync() is not None      # statistics over all ranks: (a | b) saved instead of (mean | rstd)
         ctx.has_dw = save['zd'] is not None
         ctx.has_add = addend is not None
         tensors = [x, save['z1'], save['st1'][0], save['st1'][1]]
@@ -570,7 +608,7 @@ class _UnitFn(torch.autograd.Function):
             _channel_sum(dt, m_pix, p.Cout, p.cso, p.gv['c2'])
         # ---- depthwise stage
         if ctx.has_dw:
-            dzd = _norm_bwd(p, n, hw, p.hcd, p.hcd, zd, dad, p.gammad, p.betad, mrd, p.gv['gd'], p.gv['bd'])
+            dzd = _norm_bwd(p, n, hw, p.hcd, p.hcd, zd, dad, p.gammad, p.betad, mrd, p.gv['gd'], p.gv['bd'], ctx.synced)
             if p.has_biasd:
                 _channel_sum(dzd, m_pix, p.hcd, p.hcd, p.gv['cd'])
             nb = len(p.dws)
@@ -608,7 +646,7 @@ class _UnitFn(torch.autograd.Function):
                         q._cat_grad_state['fresh'] = False
                         grads[id(q)] = None
         # ---- stage-1 norms (all branches at once)
-        dz1 = _norm_bwd(p, n, hw, p.hc1, p.hc1, z1, da1, p.gamma1, p.beta1, mr1, p.gv['g1'], p.gv['b1'])
+        dz1 = _norm_bwd(p, n, hw, p.hc1, p.hc1, z1, da1, p.gamma1, p.beta1, mr1, p.gv['g1'], p.gv['b1'], ctx.synced)
         if p.has_bias1:
             _channel_sum(dz1, m_pix, p.hc1, p.hc1, p.gv['c1'])
         # ---- first convs: weight gradients from (x, dZ1 slice)

@@ -247,6 +247,8 @@ def weight_wcs(w):
     o, i, kh, kw = w.shape
     s0, s1, s2, s3 = w.stride()
     wcs = s3 if kw > 1 else (s2 if kh > 1 else (s0 if o > 1 else cs_for(i)))
+    if o == 1 and kh == 1 and kw == 1 and i == 1:
+        return 1      # a single element: every row stride describes it
     if o == 1 and kh == 1 and kw == 1 and wcs != i:
         # a single [1][I] row with I % 4 != 0: only the strides of the size-1 dims tell a padded row (padded_weight_like / FusedAdam views keep
         # s0 = s2 = s3 = round_up(I, 4)) from a dense one (a test tensor, a checkpoint tensor, a slice of a larger storage: s3 = 1 or I) -- never

@@ -318,6 +318,15 @@ typedef struct {
 int cat_tnorm_finalize(const float* part, int scs, int G, int N, int Ho, int Wo, const float* gamma, const float* beta, int nslices,
                        const cat_nslice_t* slices, float eps, float momentum, float* scale, float* shift, float* mean, float* rstd,
                        int mstride, cat_stream_t stream);   /* mean / rstd rows are mstride floats apart (scs, or C for cat_norm_bwd) */
+/* The same norms as SynchronizedBatchNorm2d over several ranks (models/modules/sync_batchnorm/batchnorm.py:103-140): cat_tnorm_sums folds this
+ * rank's tile table (th x tw tiles, ncls entries per tile) to sums = [sum x | sum x^2] (2 * scs floats), the host all-reduces them over RCCL --
+ * ONE collective per block stage instead of one per norm layer --, and cat_tnorm_finalize_sums applies the reference's multi-replica formula
+ * (clamp = 1: inv_std = max(var, eps)^-1/2; running_var from the unbiased variance) to every norm module of the stage: scale / shift for the
+ * consumers' staging, a = inv_std, b = -mean * inv_std for cat_bn_stats_bwd / cat_bn_apply_bwd.  count = pixels over ALL ranks. */
+int cat_tnorm_sums(const float* part, int scs, int N, int Ho, int Wo, int th, int tw, int ncls, float* sums, cat_stream_t stream);
+int cat_tnorm_finalize_sums(const float* sums, double count, int scs, const float* gamma, const float* beta, int nslices,
+                            const cat_nslice_t* slices, float eps, float momentum, int clamp, float* scale, float* shift, float* a, float* b,
+                            cat_stream_t stream);
 /* cat_reflect_pad_bwd on channel slices: dxp / dx / add have their own pixel strides, C4 channels (multiple of 4) are folded and
  * `add` (optional) is added -- the skip connection's gradient joins the folded first-conv input gradient in the same pass. */
 int cat_reflect_pad_bwd2(const float* dxp, int pcs, float* dx, int dcs, const float* add, int acs, int N, int H, int W, int C4, int pad,

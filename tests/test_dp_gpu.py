@@ -85,12 +85,25 @@ def _worker_spade(rank, world, port, q, backend='gloo'):
     model = TS.build_spade_distiller(opt, sds)
     model.enable_data_parallel(red)
     batch = spade_batch(opt, int(g['h']), int(g['w']))
+    from cat_amd import fused_spade, ops
+    calls = {'n': 0}
+    plain = red.all_reduce_sum_
+
+    def counted(t):
+        calls['n'] += 1
+        return plain(t)
+    red.all_reduce_sum_ = counted          # every SynchronizedBatchNorm statistics exchange of the step (fused units + per-layer norms)
     model.set_input(parallel.shard_batch(batch, rank, world))
     model.optimize_parameters(0)
     torch.cuda.synchronize()
     m = model.modules_on_one_gpu
-    q.put((rank, {k: float(v) for k, v in model.get_current_losses().items()},
-           _probe(m.netG_student, ['fc.weight', 'up_1.shortcut.1.conv.weight', 'head_0.spade.param_free_norm.running_var', 'conv_img.weight']),
+    losses = {k: float(v) for k, v in model.get_current_losses().items()}
+    losses['__fused_train_fwd'] = float(fused_spade.STATS['train_fwd'])
+    losses['__fused_collectives'] = float(fused_spade.STATS['collectives'])
+    losses['__stat_collectives'] = float(calls['n'])
+    q.put((rank, losses,
+           _probe(m.netG_student, ['fc.weight', 'up_1.shortcut.1.conv.weight', 'head_0.spade.param_free_norm.running_var', 'conv_img.weight',
+                                   'up_3.spade.param_free_norm.running_var', 'up_2.res_ops.0.0.norm.running_var', 'up_3.dw_ops.0.1.norm.running_mean']),
            _probe(m.netD, ['discriminator_0.model0.0.weight', 'discriminator_1.model3.0.0.weight_orig'])))
     torch.distributed.destroy_process_group()
 
@@ -159,6 +172,10 @@ def _check_spade(out):
     import test_spade_gpu as TS
     from oracle import ref_spade_cpu as R
     (l0, s0, d0), (l1, s1, d1) = out[0], out[1]
+    # the student's high-resolution units ran FUSED under SynchronizedBatchNorm: one statistics exchange per unit stage (round 4)
+    assert l0['__fused_train_fwd'] > 0 and l0['__fused_collectives'] > 0, (l0['__fused_train_fwd'], l0['__fused_collectives'])
+    print('\n[dp spade] fused unit forwards %d, their statistics exchanges %d, all statistics exchanges of the step %d' %
+          (l0['__fused_train_fwd'], l0['__fused_collectives'], l0['__stat_collectives']))
     for k in s0:
         assert np.array_equal(s0[k], s1[k]), k
     for k in d0:

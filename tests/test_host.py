@@ -56,6 +56,7 @@ def test_weight_stride_of_single_row_and_single_channel_weights():
     assert ops.weight_wcs(big[1:2]) is None      # a dense row INSIDE a larger storage (round 4: was taken for a padded one; neighbours got read / written)
     fa = torch.as_strided(torch.zeros(64), (1, 6, 1, 1), (8, 1, 8, 8), 16)
     assert ops.weight_wcs(fa) == 8               # FusedAdam's view of a padded row keeps the padded strides
+    assert ops.weight_wcs(torch.zeros(1, 1, 1, 1)) == 1                                   # (a branch pruned to one channel on a one-channel input)
     one = torch.zeros(6, 1, 1, 1)
     assert ops.weight_wcs(one) == 1                                                       # what FusedAdam keeps for shape[1] == 1
     assert ops.weight_wcs(ops.padded_weight_like((6, 1, 1, 1), 'cpu')) == 4
