@@ -29,7 +29,13 @@ __global__ __launch_bounds__(256) void tnorm_finalize_kernel(const float* __rest
                                                              float* __restrict__ scale, float* __restrict__ shift,
                                                              float* __restrict__ mean_out, float* __restrict__ rstd_out, int cs,
                                                              int mstride) {
-  const int g = blockIdx.y, c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  // one WAVE per channel (4 channels per workgroup); tables of more than 1024 tiles (the image-resolution edge layers: 4096) take one
+  // WORKGROUP per channel -- `wide` -- whose four waves split the tiles and combine through LDS
+  __shared__ float xw[8];
+  const bool wide = gridDim.x >= (unsigned)cs;
+  const int wv = threadIdx.x >> 6;
+  const int g = blockIdx.y, c = wide ? (int)blockIdx.x : (int)blockIdx.x * 4 + wv, lane = wide ? (int)threadIdx.x : (int)(threadIdx.x & 63);
+  const int nl = wide ? 256 : 64;      // lanes that share the channel's tiles
   if (c >= cs) return;
   // which norm module owns channel c (padding channels between / behind the slices belong to none)
   int sl = -1;
@@ -46,19 +52,24 @@ __global__ __launch_bounds__(256) void tnorm_finalize_kernel(const float* __rest
   const int per_img = tiles, ntile = tiles * imgs_per_group;
   const float* pg = part + (int64_t)g * ntile * 2 * scs + c;
   // every lane fetches its tiles' (sum, M2) pairs up front (independent loads: one L2 round trip instead of one per tile and pass)
-  constexpr int R = 16;                  // tiles per lane kept in registers (1024 tiles); longer tables loop
+  constexpr int R = 16;                  // tiles per lane kept in registers (1024 / 4096 tiles); longer tables loop
   float s = 0.f;
   float sv[R], mv[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    const int t = lane + 64 * r;
+    const int t = lane + nl * r;
     const bool v = t < ntile;
     sv[r] = v ? pg[(int64_t)t * 2 * scs] : 0.f;
     mv[r] = v ? pg[(int64_t)t * 2 * scs + scs] : 0.f;
     s += sv[r];
   }
-  for (int t = lane + 64 * R; t < ntile; t += 64) s += pg[(int64_t)t * 2 * scs];
+  for (int t = lane + nl * R; t < ntile; t += nl) s += pg[(int64_t)t * 2 * scs];
   s = cat::wave_sum(s);
+  if (wide) {      // fixed combination order: deterministic
+    if ((threadIdx.x & 63) == 0) xw[wv] = s;
+    __syncthreads();
+    s = (xw[0] + xw[1]) + (xw[2] + xw[3]);
+  }
   const float count = (float)Ho * (float)Wo * (float)ncls * (float)imgs_per_group;
   const float mean = s / count;
   float m2 = 0.f;
@@ -69,19 +80,24 @@ __global__ __launch_bounds__(256) void tnorm_finalize_kernel(const float* __rest
   };
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    const int t = lane + 64 * r;
+    const int t = lane + nl * r;
     if (t < ntile) {
       const float n = tile_n(t);
       const float d = sv[r] / n - mean;
       m2 += mv[r] + n * d * d;
     }
   }
-  for (int t = lane + 64 * R; t < ntile; t += 64) {
+  for (int t = lane + nl * R; t < ntile; t += nl) {
     const float n = tile_n(t);
     const float d = pg[(int64_t)t * 2 * scs] / n - mean;
     m2 += pg[(int64_t)t * 2 * scs + scs] + n * d * d;
   }
   m2 = cat::wave_sum(m2);
+  if (wide) {
+    if ((threadIdx.x & 63) == 0) xw[4 + wv] = m2;
+    __syncthreads();
+    m2 = (xw[4] + xw[5]) + (xw[6] + xw[7]);
+  }
   if (lane != 0) return;
   float var = m2 / count;
   var = var > 0.f ? var : 0.f;
@@ -350,7 +366,8 @@ int cat_tnorm_finalize2(const float* part, int scs, int G, int N, int Ho, int Wo
   }
   CAT_REQUIRE(th > 0 && tw > 0 && ncls >= 1, "tnorm finalize: tile geometry");
   const int tiles_x = cdiv(Wo, tw), tiles = tiles_x * cdiv(Ho, th) * ncls;
-  tnorm_finalize_kernel<<<dim3(cdiv(scs, 4), G), 256, 0, (hipStream_t)stream>>>(part, scs, tiles, tiles_x, Ho, Wo, th, tw, ncls, G == 1 ? N : 1, gamma,
+  const int64_t ntile = (int64_t)tiles * (G == 1 ? N : 1);
+  tnorm_finalize_kernel<<<dim3(ntile > 1024 ? scs : cdiv(scs, 4), G), 256, 0, (hipStream_t)stream>>>(part, scs, tiles, tiles_x, Ho, Wo, th, tw, ncls, G == 1 ? N : 1, gamma,
                                                                                   beta, fa, eps, momentum, scale, shift, mean, rstd, scs, mstride);
   return cat::check_launch("tnorm_finalize");
 }

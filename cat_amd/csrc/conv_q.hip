@@ -137,31 +137,27 @@ __global__ __launch_bounds__(256) void qconv_kernel(const KArgs ka) {
   float* tile0 = smem;
   const int abl = P.ablate;
 
-  // staging map: slot = pixel * NCQ + quad, 256 slots per iteration -- (pixel, quad, row, column) advance incrementally (two divisions per
-  // thread instead of two per slot).  sdst: LDS float offset (-1: no slot); spq: source row + 64 (bits 0-13), source column + 64 (bits
-  // 14-27), channel quad (bits 28-31)
+  // staging map: slot = pixel * NCQ + quad; an iteration covers ACT = (256 / NCQ) * NCQ slots, so a thread keeps ONE channel quad (tid % NCQ)
+  // through all its iterations -- the staging affine's scale / shift are two registers per chunk, loaded together with the data (the first
+  // version re-loaded them per slot behind the data: +33 us on the 25 -> 40 stride-2 layer) -- and fewer than NCQ threads idle.
+  // sdst: LDS float offset (-1: no slot); spq: source row + 64 (bits 0-13), source column + 64 (bits 14-27)
   int sdst[MAXIT];
   unsigned spq[MAXIT];
+  const int dpix = 256 / NCQ, ACT = dpix * NCQ;
+  const int quad = tid % NCQ;
   {
-    const int dpix = 256 / NCQ, dq = 256 - dpix * NCQ;       // uniform
     const int drow = dpix / P.pc, dcol = dpix - drow * P.pc;
-    int pix = tid / NCQ, quad = tid - pix * NCQ;
+    int pix = tid / NCQ;
     int r = pix / P.pc, c = pix - r * P.pc;
 #pragma unroll
     for (int it = 0; it < MAXIT; ++it) {
       const int cslot = g.S == 2 ? (c & 1) * P.pch + (c >> 1) : c;
-      const bool v = pix < npix;
+      const bool v = pix < npix && tid < ACT;
       sdst[it] = v ? (r * P.pc + cslot) * PITCH + quad * 4 : -1;
-      spq[it] = (unsigned)(cy0 * g.S - P.hl + r + 64) | ((unsigned)(cx0 * g.S - P.hl + c + 64) << 14) | ((unsigned)quad << 28);
-      quad += dq;
+      spq[it] = (unsigned)(cy0 * g.S - P.hl + r + 64) | ((unsigned)(cx0 * g.S - P.hl + c + 64) << 14);
       pix += dpix;
       r += drow;
       c += dcol;
-      if (quad >= NCQ) {
-        quad -= NCQ;
-        ++pix;
-        ++c;
-      }
       if (c >= P.pc) {
         c -= P.pc;
         ++r;
@@ -185,23 +181,26 @@ __global__ __launch_bounds__(256) void qconv_kernel(const KArgs ka) {
         v = v && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
       }
       smask |= v ? (1u << it) : 0u;
-      soff[it] = v ? ((unsigned)(n * g.H + iy) * (unsigned)g.W + (unsigned)ix) * (unsigned)xcs + (spq[it] >> 28) * 4u : 0u;   // < 2^32 elements (host-checked)
+      soff[it] = v ? ((unsigned)(n * g.H + iy) * (unsigned)g.W + (unsigned)ix) * (unsigned)xcs + (unsigned)quad * 4u : 0u;   // < 2^32 elements (host-checked)
     }
   };
-  f4 sreg[MAXIT];
-  unsigned sqv = 0;             // per iteration: the slot's channel quad lies inside the segment
-  int s_cur = 0, s_c0 = 0;
+  f4 sreg[MAXIT], ssc = {1.f, 1.f, 1.f, 1.f}, ssh = {0.f, 0.f, 0.f, 0.f};
+  bool s_qv = false;            // this thread's channel quad lies inside the segment's channels of the chunk
+  int s_cur = 0;
   auto gload = [&](int s, int c0) {
-    const float* src = g.seg[s].src;
+    const cat_qseg_t& sg = g.seg[s];
+    const float* src = sg.src;
     s_cur = s;
-    s_c0 = c0;
-    sqv = 0;
+    s_qv = c0 + quad * 4 < sg.c4;
 #pragma unroll
     for (int it = 0; it < MAXIT; ++it) {
-      const bool qv = c0 + (int)(spq[it] >> 28) * 4 < g.seg[s].c4;
-      sqv |= qv ? (1u << it) : 0u;
-      const bool v = ((smask >> it) & 1u) && qv;
+      const bool v = ((smask >> it) & 1u) && s_qv;
       sreg[it] = *reinterpret_cast<const f4*>(v ? src + soff[it] + c0 : g_zero);
+    }
+    if (sg.scale) {
+      const int so = n * sg.sstride + c0 + quad * 4;
+      ssc = *reinterpret_cast<const f4*>(s_qv ? sg.scale + so : g_zero);
+      ssh = *reinterpret_cast<const f4*>(s_qv ? sg.shift + so : g_zero);
     }
   };
   auto sstore = [&](int buf) {
@@ -214,16 +213,10 @@ __global__ __launch_bounds__(256) void qconv_kernel(const KArgs ka) {
     for (int it = 0; it < MAXIT; ++it) {
       f4 v = sreg[it];
       if (aff || act) {   // wave-uniform
-        const bool ok = ((smask >> it) & 1u) && ((sqv >> it) & 1u);   // padding pixels / channels stay exactly 0
-        f4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-        if (aff) {
-          const int so = n * sg.sstride + s_c0 + (int)(spq[it] >> 28) * 4;
-          sc = *reinterpret_cast<const f4*>(ok ? sg.scale + so : g_zero);
-          sh = *reinterpret_cast<const f4*>(ok ? sg.shift + so : g_zero);
-        }
+        const bool ok = ((smask >> it) & 1u) && s_qv;   // padding pixels / channels stay exactly 0
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float a = aff ? fmaf(v[e], sc[e], sh[e]) : v[e];
+          float a = aff ? fmaf(v[e], ssc[e], ssh[e]) : v[e];
           a = a > 0.f ? a : a * neg;      // neg: 0 (ReLU), slope (LeakyReLU), 1 (none)
           v[e] = ok ? a : 0.f;
         }
@@ -562,12 +555,13 @@ static int make_plan(const cat_qconv_t* g, Plan* P) {
   // on different LDS bank quads (pitch / 4 odd) for the ds_read_b128 of 16 consecutive pixels
   const int npix = P->pr * P->pc;
   int cap = 48;
-  while (cap > 4 && (npix * (cap / 4) > 2048 || (int64_t)npix * (cap + 4) * 4 > 40 * 1024)) cap -= 4;
+  while (cap > 4 && (npix * (cap / 4) > 8 * ((256 / (cap / 4)) * (cap / 4)) || (int64_t)npix * (cap + 4) * 4 > 40 * 1024)) cap -= 4;
   const int chunks = cat::cdiv(c4max, cap);
   P->cs = cat::round_up(cat::cdiv(c4max, chunks), 4);
   P->pitch = ((P->cs / 4) & 1) ? P->cs : P->cs + 4;
   if (P->cs == 4) P->pitch = 4;
-  const int it = cat::cdiv(npix * (P->cs / 4), 256);
+  const int act_threads = (256 / (P->cs / 4)) * (P->cs / 4);      // threads that stage (a thread keeps one channel quad)
+  const int it = cat::cdiv(npix * (P->cs / 4), act_threads);
   P->maxit = it <= 2 ? 2 : (it <= 4 ? 4 : 8);
   if (it > 8) return -2;
   // programs: one per class (ncls = 4: one segment each) or one over all segments

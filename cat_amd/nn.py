@@ -314,7 +314,7 @@ class FusedSequential(nn.Sequential):
 
 # ---------------------------------------------------------------------------------------------- the generator's edge on the quad-granule kernel
 _QCONV = os.environ.get('CAT_QCONV', '1') != '0'      # A/B switch
-_QCONV_MAX_C = int(os.environ.get('CAT_QCONV_MAX_C', '48'))
+_QCONV_MAX_C = int(os.environ.get('CAT_QCONV_MAX_C', '80'))
 
 
 def _inner(x):

@@ -244,7 +244,7 @@ def test_qconv_k_segments_sum(dev):
 def test_generator_edge_through_fused_sequential(dev, norm):
     """ReflectionPad2d(3) . Conv 7x7 . norm . ReLU . Conv 3x3 / 2 . norm . ReLU . Conv 3x3 / 2 (wide) . norm . ReLU -- the down-sampling
     head of InceptionGenerator (reference inception_generator.py:37-56) with a pruned student's widths -- through cat_amd.nn.FusedSequential:
-    the first two convs take the quad-granule kernel with statistics in the epilogue.  No-grad forward (pending norms applied in the next
+    the three convs take the quad-granule kernel with statistics in the epilogue.  No-grad forward (pending norms applied in the next
     conv's staging), grad-mode forward, every gradient and the running statistics against stock torch on the host."""
     from torch import nn as tnn
     from cat_amd import nn as cnn, ops, qconv
@@ -279,10 +279,10 @@ def test_generator_edge_through_fused_sequential(dev, norm):
         try:
             with torch.no_grad():
                 y0 = net(xd)
-            assert calls['n'] == 2, 'the stem and the first stride-2 conv take the quad-granule kernel'
+            assert calls['n'] == 3, 'the stem and the two stride-2 convs take the quad-granule kernel'
             xg = xd.detach().requires_grad_(True)
             y1 = net(xg)
-            assert calls['n'] == 4
+            assert calls['n'] == 6
         finally:
             qconv.Layer.run = orig
         xr = x.clone().requires_grad_(True)
