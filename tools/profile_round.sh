@@ -6,11 +6,22 @@ set -x
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/round
 mkdir -p $OUT
+# which tree the tables are taken from: the commit is passed in (the GPU box has no .git), the kernel-source fingerprint is computed here --
+# bench.py compares it with the running sources and reports roofline.profiles_stale
+python - <<PYEOF > $OUT/meta.json
+import json, sys, datetime
+sys.argv = ['x']
+import importlib.util
+spec = importlib.util.spec_from_file_location('bench', 'bench.py'); m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+print(json.dumps({'commit': '${COMMIT:-unknown}', 'csrc_sha': m.csrc_fingerprint(), 'date': datetime.date.today().isoformat(),
+                  'command': 'COMMIT=<head> bash tools/profile_round.sh (one MI355X, through gpurun)'}, indent=1))
+PYEOF
 if [ -z "$SKIP_BENCH" ]; then
 python bench.py > $OUT/bench_c2.json 2> $OUT/bench_c2.err
 python bench.py --workload spade > $OUT/bench_spade.json 2> $OUT/bench_spade.err
 python bench.py --size 512 --batch 16 --steps 6 --warmup 2 --no-cpu-baseline > $OUT/bench_c2_512.json 2> $OUT/bench_c2_512.err
 python -c 'import __graft_entry__ as g; g.smoke()' > $OUT/smoke.log 2>&1
+python tools/qconv_bench.py > $OUT/qconv_layers.txt 2>&1
 fi
 # per-kernel durations are compared with bench.py's SERIAL roofline pass: branch streams off, no in-process event profiling
 export CAT_BRANCH_STREAMS=0
