@@ -178,7 +178,7 @@ class DataParallelReducer:
                 t.__dict__.pop('_cat_wt', None)        # transposed-filter cache of the wide dgrad tiles
             # the broadcast wrote through .data (no version bump): drop every cache derived from the old values
             for sub in m.modules():
-                for attr in ('_cat_frozen', '_cat_fold', '_cat_fused_plan', '_cat_fused_gb', '_cat_fused_main'):
+                for attr in ('_cat_frozen', '_cat_fold', '_cat_fused_plan', '_cat_fused_gb', '_cat_fused_main', '_cat_q'):
                     sub.__dict__.pop(attr, None)
         from . import optim
         optim._bump_weights_epoch()

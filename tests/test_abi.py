@@ -99,3 +99,31 @@ def test_ctypes_structs_match_the_header():
                 ctype, names = decl.split(None, 1)
                 fields += [(n.strip(), {'int': C.c_int, 'float': C.c_float}[ctype]) for n in names.split(',')]
         assert fields == list(cls._fields_), cname
+
+
+def test_qconv_structs_match_their_ctypes_mirrors(tmp_path):
+    """sizeof / offsetof of cat_qseg_t, cat_qconv_t, cat_qplan_t as the C compiler lays them out (gcc on include/cat_hip.h) against the
+    ctypes mirrors in cat_amd/_lib.py: a drifted field would only show as garbage geometry on the GPU box."""
+    import ctypes as C
+    import subprocess
+    structs = {'cat_qseg_t': _lib.QSeg, 'cat_qconv_t': _lib.QConv, 'cat_qplan_t': _lib.QPlan, 'cat_tseg_t': _lib.TSeg, 'cat_tconv_t': _lib.TConv,
+               'cat_nslice_t': _lib.NSlice}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "cat_hip.h"', 'int main(void) {']
+    for cname, cls in structs.items():
+        lines.append(f'  printf("{cname} size %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'  printf("{cname} {fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ['  return 0;', '}']
+    src = tmp_path / 'probe.c'
+    src.write_text('\n'.join(lines))
+    exe = tmp_path / 'probe'
+    subprocess.run(['gcc', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout
+    got = {}
+    for ln in out.splitlines():
+        c, f, v = ln.split()
+        got[(c, f)] = int(v)
+    for cname, cls in structs.items():
+        assert got[(cname, 'size')] == C.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert got[(cname, fname)] == getattr(cls, fname).offset, (cname, fname)
