@@ -73,7 +73,12 @@ __global__ __launch_bounds__(256) void tnorm_finalize_kernel(const float* __rest
   const float count = (float)Ho * (float)Wo * (float)ncls * (float)imgs_per_group;
   const float mean = s / count;
   float m2 = 0.f;
+  // pixels of tile t.  Planes that are whole multiples of the tile (every 64 x 64 / 128 x 128 / 256 x 256 plane of the bench) need no index
+  // arithmetic: the three integer divisions per tile were ~1 500 instructions per lane -- a quarter of this latency-bound kernel's 9 us
+  const bool full = Ho % th == 0 && Wo % tw == 0;
+  const float nfull = (float)(th * tw);
   auto tile_n = [&](int t) {
+    if (full) return nfull;
     const int ti = (t % per_img) / ncls;      // `tiles` counts entries per image: lattice tiles x classes
     const int ty = ti / tiles_x, tx = ti - ty * tiles_x;
     return (float)(min(th, Ho - ty * th) * min(tw, Wo - tx * tw));
@@ -462,8 +467,15 @@ int cat_dwm_fwd(const cat_dwm_t* g, const float* x, const float* scale, const fl
 namespace {
 
 __global__ __launch_bounds__(256) void prep_kernel(const cat_prep_job_t* __restrict__ jobs, int njobs, int accumulate) {
-  int ji = 0;
-  while (ji + 1 < njobs && (int)blockIdx.x >= jobs[ji].block0 + jobs[ji].nblocks) ++ji;
+  // the job that owns this workgroup: block0 is ascending -- binary search (the tables of all blocks of a generator are merged into one
+  // launch: ~200 jobs; a linear walk would be ~200 dependent loads in the last workgroups)
+  int lo = 0, hi = njobs - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if ((int)blockIdx.x >= jobs[mid].block0) lo = mid;
+    else hi = mid - 1;
+  }
+  const int ji = lo;
   const cat_prep_job_t& J = jobs[ji];
   const int64_t e = (int64_t)(blockIdx.x - J.block0) * 256 + threadIdx.x;
   if (J.kind == 0) {   // tconv filter stream (see pack_kernel in conv_pk.hip): one float4 per thread

@@ -245,6 +245,7 @@ class _Plan:
             arr[i].block0, arr[i].nblocks = blk, nb
             blk += nb
         t = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.dev)
+        self._last_arr = arr      # host copy (fused_block.prepare_plans merges the tables of all units of a generator into one launch)
         return t, len(jobs), blk
 
     def _pack_job(self, w, dst_ptr, mode, nn, ck, ks, nt_total, col0):
@@ -297,13 +298,24 @@ class _Plan:
         self.shapes = tuple(tuple(q.shape) for q in self.params)
         self.ids = tuple(id(q) for q in self.params)
         self.fwd_jobs = self._jobs_to_dev(fwd)
+        self.fwd_arr = self._last_arr
         self.bwd_jobs = self._jobs_to_dev(bwd)
+        self.bwd_arr = self._last_arr
+        self.tables_version = getattr(self, 'tables_version', 0) + 1
 
     def _epoch_key(self):
         trainable = any(getattr(q, '_cat_grad_view', None) is not None for q in self.params)
         return (optim.weights_epoch() if trainable else -1, tuple(q._version for q in self.params))
 
+    def ptrs_now(self):
+        return tuple(q.data_ptr() for q in self.params)
+
     def prepare(self, backward=False):
+        group = getattr(self, 'group', None)
+        if group is not None and (self.bkey if backward else self.key) != self._epoch_key():
+            # the first stale unit of a pass refreshes the operands of EVERY fused unit of the generator in one launch (round 4)
+            from . import fused_block
+            fused_block.prepare_plans(units_of(group), group, backward)
         if tuple(q.data_ptr() for q in self.params) != self.ptrs:       # FusedAdam re-housed the parameters: same layout, new addresses
             self._build_jobs()
             self.key = self.bkey = self.scatter_jobs = None
@@ -317,6 +329,17 @@ class _Plan:
             t, n, blocks = self.fwd_jobs
             L.call('cat_prep_run', ops._p(t), n, blocks, 0, ops._stream())
             self.key = key
+
+
+def units_of(generator):
+    """Plans of every fused unit (main six-branch units and gamma|beta nets) built so far under `generator`, in module order."""
+    out = []
+    for m in generator.modules():
+        for slot in ('_cat_fused_main', '_cat_fused_gb'):
+            p = m.__dict__.get(slot)
+            if p is not None:
+                out.append(p)
+    return out
 
 
 def plan_for(owner, slot, res_ops, dw_ops, cin, cout, x):

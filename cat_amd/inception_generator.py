@@ -65,6 +65,9 @@ class InceptionGenerator(BaseNetwork):
         self.up_sampling = cnn.FusedSequential(*head)
 
     def forward(self, input):
+        if self.training:      # the fused training-mode blocks refresh their packed operands once per optimizer step: all of them in one launch
+            from . import fused_block
+            fused_block.prepare_many(list(self.features))
         return self.up_sampling(self.features(self.down_sampling(input)))
 
     def get_named_block_list(self):

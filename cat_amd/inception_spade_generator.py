@@ -46,6 +46,13 @@ class InceptionSPADEGenerator(BaseNetwork):
         return width, round(width / opt.aspect_ratio)
 
     def forward(self, input, mapping_layers=[]):
+        if self.training and '_cat_prep_group' not in self.__dict__:
+            # from the second forward on (the units' plans exist): one operand-preparation launch per pass for all fused units
+            from . import fused_block, fused_spade
+            units = fused_spade.units_of(self)
+            if units:
+                fused_block.prepare_plans(units, self, False)
+                self.__dict__['_cat_prep_group'] = True
         seg = ops.conform(input)
         ret_acts = {}
 
