@@ -27,7 +27,7 @@ def main():
     ctr_names = sorted({c for r in rows for c in r[3]})
     lines = ['# rocprofv3 --pmc ' + ' '.join(ctr_names) + '  (per-launch averages, summed over XCC instances; SQ_WAVE/WAIT/ACTIVE are quad-cycles)',
              f'{"kernel":60s} {"launches":>8s} ' + ' '.join(f'{c[-22:]:>22s}' for c in ctr_names) + '   wait_any%  wait_inst%  active%  mfma_busy/wave_cyc']
-    for _, name, n, avg in rows[:16]:
+    for _, name, n, avg in rows[:24]:
         wc = avg.get('SQ_WAVE_CYCLES', 0.0) or 1.0
         extra = '   %8.1f  %9.1f  %7.1f  %10.3f' % (100 * avg.get('SQ_WAIT_ANY', 0) / wc, 100 * avg.get('SQ_WAIT_INST_ANY', 0) / wc,
                                                       100 * avg.get('SQ_ACTIVE_INST_ANY', 0) / wc, avg.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / wc)
