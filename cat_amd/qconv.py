@@ -153,8 +153,9 @@ class Layer:
         sig = (plan.cs, plan.nq, plan.nsplit, int(plan.pack_floats))
         wkey = (wcl.data_ptr(), wcl._version, optim.weights_epoch() if trainable else -1, sig, key)
         if self._pk is None or self._pk[0] != wkey:
-            buf = self._pk[1] if (self._pk is not None and self._pk[1].numel() == plan.pack_floats and self._pk[1].device == x.device) else \
-                torch.zeros(int(plan.pack_floats), device=x.device, dtype=torch.float32)
+            same_layout = self._pk is not None and self._pk[0][3:] == wkey[3:] and self._pk[1].device == x.device
+            # a new weight version re-packs in place; another geometry gets a fresh zeroed stream (its spare table rows / filter step must read 0)
+            buf = self._pk[1] if same_layout else torch.zeros(int(plan.pack_floats), device=x.device, dtype=torch.float32)
             if ct:
                 pack_conv_transpose(g, buf, wcl, wcs, nn)
             else:
