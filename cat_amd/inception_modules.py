@@ -346,8 +346,11 @@ class InceptionSPADE(nn.Module):
     def forward(self, x, segmap, fuse_act=None):
         """`fuse_act`: the activation SPADEInvertedResidualChannels applies right after (inception_modules.py:553), fused here."""
         pfn = self.param_free_norm
-        if not isinstance(pfn, cnn.BatchNorm2d):
-            raise NotImplementedError('SPADE param-free norm: (sync)batch only -- the distillation scripts use spadesyncbatch3x3')
+        instance = isinstance(pfn, cnn.InstanceNorm2d)
+        if not instance and not isinstance(pfn, cnn.BatchNorm2d):
+            raise NotImplementedError('SPADE param-free norm: (sync)batch or instance')
+        if instance and pfn.track_running_stats:
+            raise NotImplementedError('InstanceNorm2d(track_running_stats=True) is not what norm_G = spadeinstance builds')
         act, slope = cnn._act_code(fuse_act)
         seg = seg_at(segmap, x.shape[2:])
         branch_ops = list(self.res_ops) + list(self.dw_ops)
@@ -359,6 +362,8 @@ class InceptionSPADE(nn.Module):
             gb = fused_spade.apply(self, '_cat_fused_gb', self.res_ops, self.dw_ops, self.input_dim, 2 * self.output_dim, seg)
         else:
             gb = _run_branches(branch_ops, seg)
+        if instance:      # norm_G = 'spadeinstance...' (reference :414-415): per-image statistics in train and eval mode alike
+            return ops.SpadeInstanceFn.apply(x, gb, float(pfn.eps), act, slope)
         if pfn.training or not pfn.track_running_stats:
             track = pfn.training and pfn.track_running_stats
             return ops.SpadeFn.apply(x, gb, pfn.running_mean if track else None, pfn.running_var if track else None, float(pfn.eps),
@@ -403,7 +408,7 @@ class SPADEInvertedResidualChannels(nn.Module):
         elif param_free_norm_type == 'batch':
             self.norm_layer = cnn.BatchNorm2d
         elif param_free_norm_type == 'instance':
-            raise NotImplementedError('spadeinstance: the distillation scripts use spadesyncbatch3x3 (SURVEY §8a A15)')
+            self.norm_layer = cnn.InstanceNorm2d
         else:
             raise ValueError(f'{param_free_norm_type} is not a recognized param-free norm type in SPADE')
         self.semantic_nc = opt.semantic_nc

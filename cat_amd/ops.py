@@ -1071,6 +1071,63 @@ class SpadeFn(torch.autograd.Function):
         return (dx if ctx.needs_input_grad[0] else None), (dgb if ctx.needs_input_grad[1] else None), None, None, None, None, None, None
 
 
+class SpadeInstanceFn(torch.autograd.Function):
+    """InceptionSPADE modulation whose param-free norm is nn.InstanceNorm2d (norm_G = 'spadeinstance...', reference inception_modules.py:414-415,
+    746-762): y = act(instance_norm(x) * (1 + gamma) + beta), in train and eval mode alike (the layer keeps no running statistics).
+    Two library calls per pass: cat_norm_fwd in instance mode (statistics about the plane's first pixel -- torch's instance_norm does not suffer
+    the sum-of-squares cancellation on near-constant 2 x 4 planes, so neither may this) and the modulation kernels of SpadeFn on the normalised
+    tensor (a = 1, b = 0); backward: cat_spade_bwd_stats leaves d xhat in its dx buffer, cat_norm_bwd turns it into dx.  Never all-reduced.
+    No launch script uses the option."""
+
+    @staticmethod
+    def forward(ctx, x, gb, eps, act, slope):
+        _require_cuda(x)
+        x, gb = conform(x), conform(gb)
+        n, c, h, w = x.shape
+        if gb.shape != (n, 2 * c, h, w):
+            raise RuntimeError(f'SPADE: modulation maps have shape {tuple(gb.shape)}, expected {(n, 2 * c, h, w)}')
+        cs, gcs = act_cs(x), act_cs(gb)
+        st = _stream()
+        geom = (n, h * w, c, cs, L.NORM_INSTANCE, eps, 0.0, L.ACT_NONE, 0.0)
+        g = NormGeom(*geom)
+        xh = empty_act(n, c, h, w, x.device, cs)
+        mean = torch.empty((n, c), device=x.device, dtype=torch.float32)
+        rstd = torch.empty((n, c), device=x.device, dtype=torch.float32)
+        ws = workspace(L.query('cat_norm_ws_bytes', C.byref(g)), x.device)
+        L.call('cat_norm_fwd', C.byref(g), _p(x), None, None, _p(xh), _p(mean), _p(rstd), None, None, None, _p(ws), st)
+        ab = torch.zeros((2, cs), device=x.device, dtype=torch.float32)
+        ab[0].fill_(1.0)
+        y = empty_act(n, c, h, w, x.device, cs)
+        L.call('cat_spade_fwd', _p(xh), _p(ab[0]), _p(ab[1]), _p(gb), _p(y), n * h * w, c, cs, gcs, act, slope, st)
+        ctx.meta = (geom, act, slope)
+        ctx.save_for_backward(x, xh, mean, rstd, ab, gb, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, xh, mean, rstd, ab, gb, y = ctx.saved_tensors
+        geom, act, slope = ctx.meta
+        n, c, h, w = x.shape
+        cs, gcs, m = act_cs(x), act_cs(gb), n * h * w
+        dy = conform(dy)
+        if act_cs(dy) != cs:
+            raise RuntimeError('SPADE backward: gradient pixel stride differs from the input')
+        st = _stream()
+        dgb = empty_act(n, 2 * c, h, w, x.device, gcs)
+        dxh = empty_act(n, c, h, w, x.device, cs)
+        sums = torch.empty(2 * cs, device=x.device, dtype=torch.float32)
+        ws = workspace(L.query('cat_bn_ws_bytes', m, cs), x.device)
+        L.call('cat_spade_bwd_stats', _p(xh), _p(ab[0]), _p(ab[1]), _p(gb), _p(y), _p(dy), _p(dgb), _p(dxh), _p(sums), m, c, cs, gcs, act, slope,
+               _p(ws), st)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            g = NormGeom(*geom)
+            dx = empty_act(n, c, h, w, x.device, cs)
+            ws = workspace(L.query('cat_norm_ws_bytes', C.byref(g)), x.device)
+            L.call('cat_norm_bwd', C.byref(g), _p(x), _p(dxh), None, None, _p(mean), _p(rstd), _p(dx), None, None, 0, _p(ws), st)
+        return dx, (dgb if ctx.needs_input_grad[1] else None), None, None, None
+
+
 def spade_eval(x, gb, rm, rv, eps, act, slope):
     """Frozen (eval, no-grad) SPADE: the param-free norm uses the running statistics."""
     _require_cuda(x)
