@@ -29,6 +29,24 @@ def test_state_dict_keys_match_reference(tag, norm, track):
     assert D.model[0].bias is not None and (D.model[2].bias is None) == (norm == 'batch')
 
 
+def test_spadeinstance_generator_has_the_reference_state_dict():
+    """norm_G = 'spadeinstance3x3' (reference inception_modules.py:414-415): hidden / shortcut / param-free norms are InstanceNorm2d (no
+    running statistics in the state_dict), the gamma|beta nets keep SynchronizedBatchNorm2d -- keys and shapes as the reference's own
+    generator recorded them (tests/golden/spade_instance_fwd.npz)."""
+    import json
+    from argparse import Namespace
+    g = H.load('spade_instance_fwd.npz')
+    o = json.loads(str(H.load('spade_step.npz')['opt']))
+    o.update(gpu_ids=[], ngf=6, norm_G='spadeinstance3x3', data_height=128, data_width=256, data_channel=o['semantic_nc'])
+    opt = Namespace(**o)
+    from cat_amd import networks, nn as cnn
+    G = networks.define_G(opt.input_nc, 3, 6, 'inception_spade', 'instance', 0, 'xavier', 0.02, [], opt=opt)
+    assert [[k, list(v.shape)] for k, v in G.state_dict().items()] == json.loads(str(g['shapes']))
+    assert type(G.up_3.spade.param_free_norm) is cnn.InstanceNorm2d and type(G.up_3.shortcut[0]) is cnn.InstanceNorm2d
+    assert isinstance(G.up_3.spade.res_ops[0][0].norm, cnn.SynchronizedBatchNorm2d) and type(G.up_3.res_ops[0][0].norm) is cnn.InstanceNorm2d
+    assert len(G.up_3.get_first_bn()) == 6
+
+
 def test_weights_are_channels_last_after_flatten_rules():
     from cat_amd import nn as cnn, ops
     c = cnn.Conv2d(6, 4, 3)
