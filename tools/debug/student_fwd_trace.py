@@ -1,5 +1,5 @@
 """Replay the captured C2 student forward a few times (for `rocprofv3 --kernel-trace`): the per-kernel start / end timestamps show
-how the six branch streams of every block overlap.  tools/debug/trace_summary.py folds the CSV."""
+how the six branch streams of every block overlap.  tools/debug/trace_fold.py folds the CSV."""
 import argparse, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
