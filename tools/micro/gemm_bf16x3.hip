@@ -1,0 +1,243 @@
+// Prototype (round 4, exploratory -- DESIGN section 6): an LDS-fed fp32-class GEMM tile on the bf16 matrix pipe, C[M][N] = A[M][K] * B[N][K]^T with
+// PRE-SPLIT operands (x = x1 + x2 (+ x3), bf16 planes), 3 or 6 products per 16-deep slice on v_mfma_f32_32x32x16_bf16, fp32 accumulate.
+// Deliberately the simple structure of the library's wide fp32 tiles (128 x 128 workgroup tile, 2 x 2 waves of 64 x 64, BK = 64, two barriers per
+// chunk, register-staged double buffer) so that the number it prints is what a first bf16x3 conv_dgrad32d / conv_wgrad32d could expect, in
+// fp32-EQUIVALENT TFLOP/s against the 126-134 the fp32 tiles reach today (peak 157.3).  Checks itself against an fp64 product on a small case.
+//   hipcc --offload-arch=gfx950 -O3 tools/micro/gemm_bf16x3.hip -o /tmp/gemm_bf16x3 && /tmp/gemm_bf16x3
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+typedef float f16v __attribute__((ext_vector_type(16)));
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+typedef unsigned short bf16_t;
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int PLANE = 128 * BK * 2;              // bytes of one 128-row operand plane of a chunk (16 KB)
+
+// PARTS planes per operand: A planes [p][M][K], B planes [p][N][K] (bf16).  LDS: [buffer][A planes | B planes][128 rows][8 chunks of 16 B], the chunk
+// index XOR-ed with (row & 7) (a 32-row fragment read of one logical chunk then covers all eight 16-B slots of the 128-B bank row).
+template <int PARTS>
+__global__ __launch_bounds__(256) void gemm_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, float* __restrict__ C, int M, int N, int K) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int NPL = 2 * PARTS, BUF = NPL * PLANE, LD = NPL * 4;     // 16-B loads per thread and chunk
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ntn = N / BN;
+  const int m0 = (blockIdx.x / ntn) * BM, n0 = (blockIdx.x % ntn) * BN;
+  // staging map: thread -> chunk c = tid & 7 of rows (tid >> 3) + 32 j
+  const int sc = tid & 7, sr = tid >> 3;
+  u4 stg[LD];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int p = 0; p < NPL; ++p) {
+      const bf16_t* base = p < PARTS ? A + ((size_t)p * M + m0) * K : B + ((size_t)(p - PARTS) * N + n0) * K;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) stg[p * 4 + j] = *reinterpret_cast<const u4*>(base + (size_t)(sr + 32 * j) * K + k0 + sc * 8);
+    }
+  };
+  auto sstore = [&](int buf) {
+    unsigned char* d = smem + buf * BUF;
+#pragma unroll
+    for (int p = 0; p < NPL; ++p)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = sr + 32 * j;
+        *reinterpret_cast<u4*>(d + p * PLANE + r * 128 + ((sc ^ (r & 7)) << 4)) = stg[p * 4 + j];
+      }
+  };
+  f16v acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int fr = lane & 31, kg = lane >> 5;
+  auto mma = [&](int buf) {
+    const unsigned char* s = smem + buf * BUF;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf8 fa[PARTS][2], fb[PARTS][2];
+      const int c = ks * 2 + kg;
+#pragma unroll
+      for (int p = 0; p < PARTS; ++p)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int ra = wm * 64 + i * 32 + fr, rb = wn * 64 + i * 32 + fr;
+          fa[p][i] = *reinterpret_cast<const bf8*>(s + p * PLANE + ra * 128 + ((c ^ (ra & 7)) << 4));
+          fb[p][i] = *reinterpret_cast<const bf8*>(s + (PARTS + p) * PLANE + rb * 128 + ((c ^ (rb & 7)) << 4));
+        }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          if constexpr (PARTS == 3) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2][i], fb[0][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[2][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][i], fb[1][j], acc[i][j], 0, 0, 0);
+          }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][i], fb[0][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[1][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[0][j], acc[i][j], 0, 0, 0);
+        }
+    }
+  };
+  const int nk = K / BK;
+  gload(0);
+  sstore(0);
+  __syncthreads();
+  for (int kc = 0; kc < nk; ++kc) {
+    // two LDS buffers with two planes per operand (128 KB); one with three (96 KB: the next chunk waits in registers for a second barrier)
+    const int buf = PARTS == 2 ? (kc & 1) : 0;
+    if (kc + 1 < nk) gload((kc + 1) * BK);      // in flight behind this chunk's MFMA stream
+    mma(buf);
+    if (PARTS == 3) __syncthreads();
+    if (kc + 1 < nk) sstore(PARTS == 2 ? buf ^ 1 : 0);      // two buffers: buf ^ 1 was last read before the previous barrier
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg, col = n0 + wn * 64 + j * 32 + fr;
+        C[(size_t)row * N + col] = acc[i][j][r];
+      }
+}
+
+static bf16_t bf16_rne(float x) {
+  unsigned u;
+  memcpy(&u, &x, 4);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+static float bf16_f32(bf16_t h) {
+  unsigned u = (unsigned)h << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+static void split_planes(const std::vector<float>& x, int parts, std::vector<bf16_t>& out) {
+  out.resize((size_t)parts * x.size());
+  for (size_t i = 0; i < x.size(); ++i) {
+    float r = x[i];
+    for (int p = 0; p < parts; ++p) {
+      const bf16_t h = bf16_rne(r);
+      out[(size_t)p * x.size() + i] = h;
+      r -= bf16_f32(h);
+    }
+  }
+}
+
+__global__ void fill_kernel(bf16_t* p, size_t n, unsigned seed) {      // random-like bf16 bit patterns in [-2, 2): timing runs only
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    unsigned h = (unsigned)i * 2654435761u + seed;
+    h ^= h >> 15;
+    h *= 2246822519u;
+    h ^= h >> 13;
+    p[i] = (bf16_t)((h & 0x80ffu) | (((h >> 16) & 1u ? 0x3f00u : 0x3f80u)));
+  }
+}
+
+template <int PARTS>
+static void launch(const bf16_t* A, const bf16_t* B, float* C, int M, int N, int K) {
+  const int lds = (PARTS == 2 ? 2 : 1) * 2 * PARTS * PLANE, grid = (M / BM) * (N / BN);
+  (void)hipFuncSetAttribute((const void*)gemm_kernel<PARTS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  gemm_kernel<PARTS><<<grid, 256, lds>>>(A, B, C, M, N, K);
+}
+
+template <int PARTS>
+static void check(int M, int N, int K) {
+  std::vector<float> hA((size_t)M * K), hB((size_t)N * K);
+  for (auto& v : hA) v = (float)(rand() & 0xffffff) / 16777216.f * 2.f - 0.7f;      // asymmetric operands, non-zero means
+  for (auto& v : hB) v = (float)(rand() & 0xffffff) / 16777216.f * 3.f - 1.1f;
+  std::vector<bf16_t> pA, pB;
+  split_planes(hA, PARTS, pA);
+  split_planes(hB, PARTS, pB);
+  bf16_t *A, *B;
+  float* C;
+  (void)hipMalloc(&A, pA.size() * 2);
+  (void)hipMalloc(&B, pB.size() * 2);
+  (void)hipMalloc(&C, (size_t)M * N * 4);
+  (void)hipMemcpy(A, pA.data(), pA.size() * 2, hipMemcpyHostToDevice);
+  (void)hipMemcpy(B, pB.data(), pB.size() * 2, hipMemcpyHostToDevice);
+  launch<PARTS>(A, B, C, M, N, K);
+  if (hipDeviceSynchronize() != hipSuccess) {
+    printf("launch failed: %s\n", hipGetErrorString(hipGetLastError()));
+    return;
+  }
+  std::vector<float> hC((size_t)M * N);
+  (void)hipMemcpy(hC.data(), C, hC.size() * 4, hipMemcpyDeviceToHost);
+  double worst = 0, worst32 = 0;
+  for (int i = 0; i < M; i += 3)
+    for (int j = 0; j < N; j += 5) {
+      double s = 0, sa = 0;
+      float s32 = 0.f;
+      for (int k = 0; k < K; ++k) {
+        const double t = (double)hA[(size_t)i * K + k] * hB[(size_t)j * K + k];
+        s += t;
+        sa += fabs(t);
+        s32 = fmaf(hA[(size_t)i * K + k], hB[(size_t)j * K + k], s32);
+      }
+      worst = fmax(worst, fabs(hC[(size_t)i * N + j] - s) / sa);
+      worst32 = fmax(worst32, fabs((double)s32 - s) / sa);
+    }
+  printf("check %d x %d x %d, %d products: worst |C - exact| / sum|a b| = %.3e  [host fp32 fma chain %.3e]\n", M, N, K, PARTS == 3 ? 6 : 3, worst, worst32);
+  (void)hipFree(A);
+  (void)hipFree(B);
+  (void)hipFree(C);
+}
+
+template <int PARTS>
+static void timeit(int M, int N, int K) {
+  bf16_t *A, *B;
+  float* C;
+  const size_t na = (size_t)PARTS * M * K, nb = (size_t)PARTS * N * K;
+  (void)hipMalloc(&A, na * 2);
+  (void)hipMalloc(&B, nb * 2);
+  (void)hipMalloc(&C, (size_t)M * N * 4);
+  fill_kernel<<<2048, 256>>>(A, na, 1u);
+  fill_kernel<<<2048, 256>>>(B, nb, 77u);
+  launch<PARTS>(A, B, C, M, N, K);
+  if (hipDeviceSynchronize() != hipSuccess) {
+    printf("launch failed: %s\n", hipGetErrorString(hipGetLastError()));
+    return;
+  }
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  const int reps = 5;
+  (void)hipEventRecord(e0);
+  for (int r = 0; r < reps; ++r) launch<PARTS>(A, B, C, M, N, K);
+  (void)hipEventRecord(e1);
+  (void)hipEventSynchronize(e1);
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  ms /= reps;
+  const double flop = 2.0 * M * N * K;
+  printf("time  %6d x %5d x %5d, %d products, %5d workgroups: %8.1f us  %6.1f fp32-equivalent TFLOP/s  (%7.1f bf16 TFLOP/s)\n", M, N, K, PARTS == 3 ? 6 : 3,
+         (M / BM) * (N / BN), ms * 1e3, flop / ms * 1e-9, flop * (PARTS == 3 ? 6 : 3) / ms * 1e-9);
+  (void)hipFree(A);
+  (void)hipFree(B);
+  (void)hipFree(C);
+}
+
+int main() {
+  srand(11);
+  check<2>(256, 384, 512);
+  check<3>(256, 384, 512);
+  // the PatchGAN layers' GEMM shapes at batch 16 (pixels x Cout x taps * Cin) and a square case
+  timeit<2>(65536, 256, 2048);
+  timeit<2>(16384, 512, 4096);
+  timeit<2>(15360, 512, 8192);
+  timeit<2>(8192, 8192, 4096);
+  timeit<3>(65536, 256, 2048);
+  timeit<3>(15360, 512, 8192);
+  timeit<3>(8192, 8192, 4096);
+  return 0;
+}
