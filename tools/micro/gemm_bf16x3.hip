@@ -144,6 +144,60 @@ __global__ void fill_kernel(bf16_t* p, size_t n, unsigned seed) {      // random
   }
 }
 
+// fp32 tensor -> PARTS bf16 planes (round to nearest even of the running residual): the pass a producer-side epilogue would otherwise do
+template <int PARTS>
+__global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ x, bf16_t* __restrict__ out, size_t n4) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  typedef unsigned short us4 __attribute__((ext_vector_type(4)));
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    f4 r = reinterpret_cast<const f4*>(x)[i];
+#pragma unroll
+    for (int p = 0; p < PARTS; ++p) {
+      us4 h;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        unsigned u = __float_as_uint(r[e]);
+        u += 0x7fffu + ((u >> 16) & 1u);
+        h[e] = (unsigned short)(u >> 16);
+        r[e] -= __uint_as_float((unsigned)h[e] << 16);
+      }
+      reinterpret_cast<us4*>(out + (size_t)p * n4 * 4)[i] = h;
+    }
+  }
+}
+
+template <int PARTS>
+static void time_split(size_t n) {
+  float* x;
+  bf16_t* o;
+  (void)hipMalloc(&x, n * 4);
+  (void)hipMalloc(&o, n * 2 * PARTS);
+  std::vector<float> h(1 << 20);
+  for (auto& v : h) v = (float)(rand() & 0xffffff) / 16777216.f * 4.f - 1.3f;
+  for (size_t off = 0; off < n; off += h.size()) (void)hipMemcpy(x + off, h.data(), (n - off < h.size() ? n - off : h.size()) * 4, hipMemcpyHostToDevice);
+  split_kernel<PARTS><<<4096, 256>>>(x, o, n / 4);
+  (void)hipDeviceSynchronize();
+  std::vector<bf16_t> dev((size_t)PARTS * h.size()), ref;
+  for (int p = 0; p < PARTS; ++p) (void)hipMemcpy(dev.data() + (size_t)p * h.size(), o + (size_t)p * n, h.size() * 2, hipMemcpyDeviceToHost);
+  split_planes(h, PARTS, ref);
+  size_t bad = 0;
+  for (size_t i = 0; i < dev.size(); ++i) bad += dev[i] != ref[i];
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  (void)hipEventRecord(e0);
+  for (int r = 0; r < 10; ++r) split_kernel<PARTS><<<4096, 256>>>(x, o, n / 4);
+  (void)hipEventRecord(e1);
+  (void)hipEventSynchronize(e1);
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  ms /= 10;
+  printf("split %zu MB fp32 -> %d bf16 planes: %6.1f us  %5.2f TB/s (read + written)   device vs host split: %zu of %zu values differ\n", n * 4 >> 20, PARTS, ms * 1e3,
+         (double)n * (4 + 2 * PARTS) / ms * 1e-9, bad, dev.size());
+  (void)hipFree(x);
+  (void)hipFree(o);
+}
+
 template <int PARTS>
 static void launch(const bf16_t* A, const bf16_t* B, float* C, int M, int N, int K) {
   const int lds = (PARTS == 2 ? 2 : 1) * 2 * PARTS * PLANE, grid = (M / BM) * (N / BN);
@@ -239,5 +293,8 @@ int main() {
   timeit<3>(65536, 256, 2048);
   timeit<3>(15360, 512, 8192);
   timeit<3>(8192, 8192, 4096);
+  time_split<2>((size_t)16 * 128 * 128 * 128);      // PatchGAN layer-2 input at batch 16 (134 MB)
+  time_split<3>((size_t)16 * 128 * 128 * 128);
+  time_split<2>((size_t)16 * 32 * 32 * 512);          // layer-4 input (33 MB)
   return 0;
 }
