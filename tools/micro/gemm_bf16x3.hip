@@ -110,6 +110,97 @@ __global__ __launch_bounds__(256) void gemm_kernel(const bf16_t* __restrict__ A,
       }
 }
 
+// The same tile with the operand planes DMA-ed straight into LDS (buffer_load_dwordx4 ... lds, as conv_fwd32d / dgrad32d / wgrad32d stage their fp32 tiles):
+// one instruction writes 8 rows x 128 B lane-linearly, so the XOR swizzle is applied to the SOURCE chunk a lane fetches; no staging registers, no
+// ds_write pass, ONE barrier per chunk (issue next chunk -> MFMA stream of this one -> vmcnt(0) -> barrier).
+template <int PARTS>
+__global__ __launch_bounds__(256) void gemm_dma_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, float* __restrict__ C, int M, int N, int K) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  typedef __attribute__((address_space(3))) void* lds_t;
+  constexpr int NPL = 2 * PARTS, BUF = NPL * PLANE;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ntn = N / BN;
+  const int m0 = (blockIdx.x / ntn) * BM, n0 = (blockIdx.x % ntn) * BN;
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(A), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(B), 0, 0x7fffffff, 0x00020000);
+  // wave w, instruction i -> rows (w * 4 + i) * 8 + (lane >> 3) of a plane; LDS slot lane & 7 <- source chunk slot ^ (row & 7)
+  unsigned voA[4], voB[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (wave * 4 + i) * 8 + (lane >> 3);
+    const unsigned c = (unsigned)((lane & 7) ^ (row & 7));
+    voA[i] = ((unsigned)(m0 + row) * (unsigned)K + c * 8u) * 2u;
+    voB[i] = ((unsigned)(n0 + row) * (unsigned)K + c * 8u) * 2u;
+  }
+  const unsigned plA = (unsigned)M * (unsigned)K * 2u, plB = (unsigned)N * (unsigned)K * 2u;     // bytes between planes
+  auto issue = [&](int buf, int k0) {
+    unsigned char* d = smem + buf * BUF + wave * 4 * 1024;
+#pragma unroll
+    for (int p = 0; p < PARTS; ++p) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_t)(d + p * PLANE + i * 1024), 16, voA[i], (unsigned)p * plA + (unsigned)k0 * 2u, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_t)(d + (PARTS + p) * PLANE + i * 1024), 16, voB[i], (unsigned)p * plB + (unsigned)k0 * 2u, 0, 0);
+    }
+  };
+  f16v acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int fr = lane & 31, kg = lane >> 5;
+  auto mma = [&](int buf) {
+    const unsigned char* s = smem + buf * BUF;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf8 fa[PARTS][2], fb[PARTS][2];
+      const int c = ks * 2 + kg;
+#pragma unroll
+      for (int p = 0; p < PARTS; ++p)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int ra = wm * 64 + i * 32 + fr, rb = wn * 64 + i * 32 + fr;
+          fa[p][i] = *reinterpret_cast<const bf8*>(s + p * PLANE + ra * 128 + ((c ^ (ra & 7)) << 4));
+          fb[p][i] = *reinterpret_cast<const bf8*>(s + (PARTS + p) * PLANE + rb * 128 + ((c ^ (rb & 7)) << 4));
+        }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][i], fb[0][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[1][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[0][j], acc[i][j], 0, 0, 0);
+        }
+    }
+  };
+  const int nk = K / BK;
+  issue(0, 0);
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  for (int kc = 0; kc + 1 < nk; ++kc) {
+    const int buf = kc & 1;
+    issue(buf ^ 1, (kc + 1) * BK);      // buf ^ 1 was released by the barrier below
+    mma(buf);
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+  }
+  mma((nk - 1) & 1);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg, col = n0 + wn * 64 + j * 32 + fr;
+        C[(size_t)row * N + col] = acc[i][j][r];
+      }
+}
+
 static bf16_t bf16_rne(float x) {
   unsigned u;
   memcpy(&u, &x, 4);
@@ -198,9 +289,15 @@ static void time_split(size_t n) {
   (void)hipFree(o);
 }
 
+static bool g_dma = false;      // the direct-to-LDS variant (two planes per operand only)
 template <int PARTS>
 static void launch(const bf16_t* A, const bf16_t* B, float* C, int M, int N, int K) {
   const int lds = (PARTS == 2 ? 2 : 1) * 2 * PARTS * PLANE, grid = (M / BM) * (N / BN);
+  if (g_dma && PARTS == 2) {
+    (void)hipFuncSetAttribute((const void*)gemm_dma_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    gemm_dma_kernel<2><<<grid, 256, lds>>>(A, B, C, M, N, K);
+    return;
+  }
   (void)hipFuncSetAttribute((const void*)gemm_kernel<PARTS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   gemm_kernel<PARTS><<<grid, 256, lds>>>(A, B, C, M, N, K);
 }
@@ -241,7 +338,7 @@ static void check(int M, int N, int K) {
       worst = fmax(worst, fabs(hC[(size_t)i * N + j] - s) / sa);
       worst32 = fmax(worst32, fabs((double)s32 - s) / sa);
     }
-  printf("check %d x %d x %d, %d products: worst |C - exact| / sum|a b| = %.3e  [host fp32 fma chain %.3e]\n", M, N, K, PARTS == 3 ? 6 : 3, worst, worst32);
+  printf("check%s %d x %d x %d, %d products: worst |C - exact| / sum|a b| = %.3e  [host fp32 fma chain %.3e]\n", g_dma && PARTS == 2 ? " (direct-to-LDS)" : "", M, N, K, PARTS == 3 ? 6 : 3, worst, worst32);
   (void)hipFree(A);
   (void)hipFree(B);
   (void)hipFree(C);
@@ -274,7 +371,7 @@ static void timeit(int M, int N, int K) {
   (void)hipEventElapsedTime(&ms, e0, e1);
   ms /= reps;
   const double flop = 2.0 * M * N * K;
-  printf("time  %6d x %5d x %5d, %d products, %5d workgroups: %8.1f us  %6.1f fp32-equivalent TFLOP/s  (%7.1f bf16 TFLOP/s)\n", M, N, K, PARTS == 3 ? 6 : 3,
+  printf("time%s  %6d x %5d x %5d, %d products, %5d workgroups: %8.1f us  %6.1f fp32-equivalent TFLOP/s  (%7.1f bf16 TFLOP/s)\n", g_dma && PARTS == 2 ? " (direct-to-LDS)" : "", M, N, K, PARTS == 3 ? 6 : 3,
          (M / BM) * (N / BN), ms * 1e3, flop / ms * 1e-9, flop * (PARTS == 3 ? 6 : 3) / ms * 1e-9);
   (void)hipFree(A);
   (void)hipFree(B);
@@ -293,6 +390,13 @@ int main() {
   timeit<3>(65536, 256, 2048);
   timeit<3>(15360, 512, 8192);
   timeit<3>(8192, 8192, 4096);
+  g_dma = true;
+  check<2>(256, 384, 512);
+  timeit<2>(65536, 256, 2048);
+  timeit<2>(16384, 512, 4096);
+  timeit<2>(15360, 512, 8192);
+  timeit<2>(8192, 8192, 4096);
+  g_dma = false;
   time_split<2>((size_t)16 * 128 * 128 * 128);      // PatchGAN layer-2 input at batch 16 (134 MB)
   time_split<3>((size_t)16 * 128 * 128 * 128);
   time_split<2>((size_t)16 * 32 * 32 * 512);          // layer-4 input (33 MB)
