@@ -27,6 +27,7 @@ struct Geom {
   int nsplit, gper;        // row groups per split
 };
 
+template <bool SWZ>
 __global__ __launch_bounds__(256) void wgrad_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, float* __restrict__ part, const Geom g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   typedef __attribute__((address_space(3))) void* lds_t;
@@ -52,7 +53,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const bf16_t* __restrict__ x
     pr[i] = kk / g.Wc;
     pc[i] = kk - pr[i] * g.Wc;
   }
-  const unsigned slot = (unsigned)(lane & 15) * 16u;
+  // LDS slot lane & 15 of pixel row r holds the row's 16-byte piece (lane & 15) ^ ((r & 3) << 2): the four pixel rows one transposed read gathers
+  // (256 bytes = one bank row apart) then sit in four different 32-byte blocks, and the two 16-lane groups of a 32-lane pass in the odd / even ones
+  const unsigned slot = (unsigned)((lane & 15) ^ (SWZ ? (lane >> 4) << 2 : 0)) * 16u;
   const int rgroups = (g.Ho + g.R - 1) / g.R;
   int grp = split * g.gper;                      // walk state of the NEXT chunk to fetch
   const int gend = min(g.G, grp + g.gper);
@@ -93,8 +96,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const bf16_t* __restrict__ x
   // fragment read: lane l, s = l & 15 supplies the address of pixel row (s >> 2) (+ 4 for the second read), channels 16 * ((l >> 4) & 1) + 4 * (s & 3) ..+3
   const int s = lane & 15, kg = lane >> 5;
   const int toff = (kg * 8 + (s >> 2)) * 256 + (16 * ((lane >> 4) & 1) + 4 * (s & 3)) * 2;
+  const int xsw = SWZ ? ((s >> 2) & 3) << 6 : 0;
   auto frag = [&](const unsigned char* plane, int ks, int ch) {
-    const unsigned char* a = plane + ks * 16 * 256 + ch * 2 + toff;
+    const unsigned char* a = plane + ks * 16 * 256 + ((ch * 2) ^ xsw) + toff;
     const s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(a));
     const s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(a + 4 * 256));
     const s8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -198,11 +202,17 @@ static Geom geom(int N, int H, int W, int Cin, int Cout, int k, int S, int p, in
   return g;
 }
 
+static bool g_swz = false;      // XOR-swizzled LDS rows (see the staging map)
 static void launch(const bf16_t* x, const bf16_t* dy, float* part, const Geom& g) {
   const int lds = 2 * 4 * PLANE;
   const dim3 grid((g.Cin / 128) * (g.Cout / 128) * g.k * g.k, g.nsplit);
-  (void)hipFuncSetAttribute((const void*)wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  wgrad_kernel<<<grid, 256, lds>>>(x, dy, part, g);
+  if (g_swz) {
+    (void)hipFuncSetAttribute((const void*)wgrad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    wgrad_kernel<true><<<grid, 256, lds>>>(x, dy, part, g);
+  } else {
+    (void)hipFuncSetAttribute((const void*)wgrad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    wgrad_kernel<false><<<grid, 256, lds>>>(x, dy, part, g);
+  }
 }
 
 static void check(const Geom& g) {
@@ -258,7 +268,7 @@ static void check(const Geom& g) {
     }
     worst = fmax(worst, fabs(sum - ref[i]) / fmax(mag[i], 1e-30));
   }
-  printf("check N %d  x %dx%dx%d  dy %dx%dx%d  k%d s%d p%d, chunk %d x %d, %d splits: worst |dW - exact| / sum|terms| = %.3e, unwritten %zu\n", g.N, g.H, g.W, g.Cin, g.Ho,
+  printf("check%s N %d  x %dx%dx%d  dy %dx%dx%d  k%d s%d p%d, chunk %d x %d, %d splits: worst |dW - exact| / sum|terms| = %.3e, unwritten %zu\n", g_swz ? " (swizzled)" : "", g.N, g.H, g.W, g.Cin, g.Ho,
          g.Wo, g.Cout, g.k, g.S, g.p, g.R, g.Wc, g.nsplit, worst, nan);
   (void)hipFree(x);
   (void)hipFree(dy);
@@ -291,8 +301,8 @@ static void timeit(const Geom& g, const char* name) {
   (void)hipEventElapsedTime(&ms, e0, e1);
   ms /= reps;
   const double flop = 2.0 * g.N * g.Ho * g.Wo * g.Cout * g.k * g.k * g.Cin;
-  printf("time  %-28s %d splits, %5d workgroups: %8.1f us  %6.1f fp32-equivalent TFLOP/s   (conv_wgrad32d in fp32: 0.80 of 157.3 = 126; partial sums reduced separately in both)\n",
-         name, g.nsplit, (g.Cin / 128) * (g.Cout / 128) * g.k * g.k * g.nsplit, ms * 1e3, flop / ms * 1e-9);
+  printf("time%s  %-28s %d splits, %5d workgroups: %8.1f us  %6.1f fp32-equivalent TFLOP/s   (conv_wgrad32d in fp32: 0.80 of 157.3 = 126; partial sums reduced separately in both)\n",
+         g_swz ? " (swizzled)" : "", name, g.nsplit, (g.Cin / 128) * (g.Cout / 128) * g.k * g.k * g.nsplit, ms * 1e3, flop / ms * 1e-9);
   (void)hipFree(x);
   (void)hipFree(dy);
   (void)hipFree(part);
@@ -303,6 +313,13 @@ int main() {
   check(geom(2, 16, 16, 128, 128, 4, 2, 1, 2));      // 8 x 8 output: one chunk per image
   check(geom(1, 12, 20, 128, 256, 4, 1, 1, 3));      // stride 1, 11 x 19 output: chunks of 2 x 32 with ragged rows and columns
   check(geom(3, 20, 70, 256, 128, 4, 2, 1, 4));      // 10 x 35 output: chunks of 1 x 64
+  timeit(geom(16, 128, 128, 128, 256, 4, 2, 1, 16), "D layer 2 (256 x 128, s2)");
+  timeit(geom(16, 64, 64, 256, 512, 4, 2, 1, 4), "D layer 3 (512 x 256, s2)");
+  timeit(geom(16, 32, 32, 512, 512, 4, 1, 1, 2), "D layer 4 (512 x 512, s1)");
+  g_swz = true;
+  check(geom(2, 16, 16, 128, 128, 4, 2, 1, 2));
+  check(geom(1, 12, 20, 128, 256, 4, 1, 1, 3));
+  check(geom(3, 20, 70, 256, 128, 4, 2, 1, 4));
   timeit(geom(16, 128, 128, 128, 256, 4, 2, 1, 16), "D layer 2 (256 x 128, s2)");
   timeit(geom(16, 64, 64, 256, 512, 4, 2, 1, 4), "D layer 3 (512 x 256, s2)");
   timeit(geom(16, 32, 32, 512, 512, 4, 1, 1, 2), "D layer 4 (512 x 512, s1)");
