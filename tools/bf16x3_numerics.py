@@ -6,7 +6,7 @@ decision to build one rests on numbers: the oracle's C2 headline step (256 x 256
 run in fp64, in fp32, and in fp32 with the discriminator's three 128/256/512-channel 4x4 convolutions -- forward, data gradient and weight
 gradient -- replaced by the split form (each bf16 x bf16 product is exact in fp32, so fp32 convolutions of the split operands ARE the
 arithmetic of the matrix pipe up to summation order).  Printed in the units of tests/test_spade_gpu.py::check_grads.
-    python tools/bf16x3_numerics.py [size] [batch] [terms] [which]      terms: 1 | 2 | 3 (default) | 4 | 6, see combine(); which: subset of 'fdw' (the discriminator's wide layers: forward / dgrad / wgrad; 'F' = forward with 6 terms whatever [terms] says) and 't' (every dense conv of the frozen teacher)"""
+    python tools/bf16x3_numerics.py [size] [batch] [terms] [which] [c2 | c3]      terms: 1 | 2 | 3 (default) | 4 | 6, see combine(); which: subset of 'fdw' (the discriminator's wide layers: forward / dgrad / wgrad; 'F' = forward with 6 terms whatever [terms] says) and 't' (every dense conv of the frozen teacher)"""
 import os
 import sys
 
@@ -110,15 +110,14 @@ def report(name, got, ref64, own32=None):
 def main():
     global TERMS, WHICH
     from oracle import detfill, ref_cpu
-    from oracle_fp64_calibration import c2_state_dicts, to64
+    from oracle_fp64_calibration import oracle_cfg, state_dicts, to64
     size = int(sys.argv[1]) if len(sys.argv) > 1 else 256
     nb = int(sys.argv[2]) if len(sys.argv) > 2 else 2
     TERMS = int(sys.argv[3]) if len(sys.argv) > 3 else 3
     WHICH = sys.argv[4] if len(sys.argv) > 4 else 'fdw'
-    opt, T, S, D = c2_state_dicts()
-    ncfg = {'norm': 'batch', 'eps': opt.norm_epsilon, 'momentum': opt.norm_momentum}
-    cfg = dict(T=ncfg, S=ncfg, D=ncfg, dataset_mode='aligned', gan_mode='hinge', lambda_recon=100.0, lambda_distill=1.3, lambda_gan=1.0, lr=opt.lr,
-               beta1=opt.beta1)
+    which = sys.argv[5] if len(sys.argv) > 5 else 'c2'
+    opt, T, S, D = state_dicts(which)
+    cfg = oracle_cfg(opt)
     A, B = detfill.images((nb, 3, size, size), 71), detfill.images((nb, 3, size, size), 72)
     st64 = ref_cpu.DistillState(to64(T), to64(S), to64(D), cfg)
     ref_cpu.distill_step(st64, A.double(), B.double())
@@ -130,7 +129,7 @@ def main():
         ref_cpu.distill_step(stx, A, B)
     finally:
         ref_cpu.F.conv2d = _conv
-    print('C2 step @%dx%d batch %d; %d discriminator convolutions (x3: forward, dgrad, wgrad) in %d-term split-bf16 arithmetic, applied to [%s]; teacher convolutions in split form: %d' % (size, size, nb, STATS['calls'], TERMS, WHICH, STATS.get('teacher', 0)))
+    print(which.upper() + ' step @%dx%d batch %d; %d discriminator convolutions (x3: forward, dgrad, wgrad) in %d-term split-bf16 arithmetic, applied to [%s]; teacher convolutions in split form: %d' % (size, size, nb, STATS['calls'], TERMS, WHICH, STATS.get('teacher', 0)))
     for k in st64.losses:
         r = abs(st64.losses[k]) + 1e-30
         print('  loss %-11s fp64 %+.8f   split: %.2e   plain fp32: %.2e   (relative)' % (k, st64.losses[k], abs(stx.losses[k] - st64.losses[k]) / r, abs(st32.losses[k] - st64.losses[k]) / r))

@@ -14,23 +14,41 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 
-def c2_state_dicts():
-    import helpers as H
+CONFIGS = {      # bench.py's C2 / C3 (BASELINE configs[1] / configs[2] per GPU)
+    'c2': dict(opt=dict(norm='batch', track=True, ndf=128, dataset_mode='aligned', gan_mode='hinge', lambda_recon=100.0, lambda_distill=1.3),
+               target_flops=4.6e9, d_in=6),
+    'c3': dict(opt=dict(norm='instance', track=False, ndf=64, dataset_mode='unaligned', gan_mode='lsgan', lambda_recon=5.0, lambda_distill=1.0),
+               target_flops=2.6e9, d_in=3),
+}
+
+
+def state_dicts(which='c2'):
+    import copy
     from cat_amd import networks, prune, synthetic
-    opt = synthetic.default_options(norm='batch', track=True, ndf=128, dataset_mode='aligned', gan_mode='hinge', lambda_recon=100.0,
-                                    lambda_distill=1.3, target_flops=4.6e9, prune_cin_lb=16, student_ngf=32, gpu_ids=[])
+    c = CONFIGS[which]
+    opt = synthetic.default_options(**c['opt'], target_flops=c['target_flops'], prune_cin_lb=16, student_ngf=32, gpu_ids=[])
     torch.manual_seed(233)
-    T = networks.define_G(3, 3, 64, 'inception_9blocks', 'batch', 0, 'normal', 0.02, [], opt=opt)
+    norm = c['opt']['norm']
+    T = networks.define_G(3, 3, 64, 'inception_9blocks', norm, 0, 'normal', 0.02, [], opt=opt)
     T.load_state_dict(synthetic.fill_state_dict(T.state_dict(), synthetic.SEED_TEACHER, gamma_abs_normal=True))
     T.eval()
-    import copy
-    thr, _ = prune.search_threshold(T, 4.6e9, opt)
+    thr, _ = prune.search_threshold(T, c['target_flops'], opt)
     S = copy.deepcopy(T)
     prune._apply_structure(S, T, thr, opt, copy_weights=True)
     S = networks.init_net(S, 'normal', 0.02, [])
-    D = networks.define_D(6, 128, 'n_layers', 3, 'batch', 'normal', 0.02, [], opt=opt)
+    D = networks.define_D(c['d_in'], c['opt']['ndf'], 'n_layers', 3, norm, 'normal', 0.02, [], opt=opt)
     cpu = lambda net: {k: v.detach().clone() for k, v in net.state_dict().items()}
     return opt, cpu(T), cpu(S), cpu(D)
+
+
+def c2_state_dicts():
+    return state_dicts('c2')
+
+
+def oracle_cfg(opt):
+    ncfg = {'norm': opt.norm, 'eps': opt.norm_epsilon, 'momentum': opt.norm_momentum}
+    return dict(T=ncfg, S=ncfg, D=ncfg, dataset_mode=opt.dataset_mode, gan_mode=opt.gan_mode, lambda_recon=opt.lambda_recon,
+                lambda_distill=opt.lambda_distill, lambda_gan=1.0, lr=opt.lr, beta1=opt.beta1)
 
 
 def to64(sd):
