@@ -247,3 +247,35 @@ def test_remove_spectral_norm_matches_torch():
     import pytest
     with pytest.raises(ValueError):
         cnn.remove_spectral_norm(mine)
+
+
+def test_split_bf16_emulation_properties():
+    """tools/bf16x3_numerics.py restates split-bf16 matrix arithmetic with fp32 convolutions (exploratory).  What that rests on:
+    the bf16 parts of an fp32 number sum back to it exactly (three parts) or to 2^-16 (two), products of parts are exact in fp32, and the
+    1 / 3 / 6-product forms of a dot product land in the error classes 2^-8 / 2^-16 / 2^-24 of sum |a b|."""
+    import importlib.util
+    import torch.nn.functional as F
+    spec = importlib.util.spec_from_file_location('bf16x3_numerics', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                                'tools', 'bf16x3_numerics.py'))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(4096, generator=g) * torch.logspace(-6, 6, 4096)
+    a1, a2, a3 = m.split(x, 3)
+    assert torch.equal(a1 + a2 + a3, x)                                   # three bf16 parts carry all 24 bits
+    h1, h2 = m.split(x, 2)
+    assert float(((h1 + h2 - x).abs() / x.abs()).max()) <= 2.0 ** -16
+    for t in (a1, a2, a3):
+        assert torch.equal(t.to(torch.bfloat16).to(torch.float32), t)     # each part IS a bf16 value
+    p = (a1.double() * a2.double())
+    assert torch.equal((a1 * a2).double(), p)                             # 8-bit x 8-bit mantissas: the fp32 product is exact
+    a = torch.randn(8, 64, 9, 9, generator=g)
+    w = torch.randn(16, 64, 3, 3, generator=g)
+    exact = F.conv2d(a.double(), w.double())
+    scale = F.conv2d(a.double().abs(), w.double().abs())
+    err = {}
+    for terms in (1, 3, 6):
+        m.TERMS = terms
+        y = m.combine(lambda u, v: F.conv2d(u, v), a, w)
+        err[terms] = float(((y.double() - exact).abs() / scale).max())
+    assert 2.0 ** -12 < err[1] < 2.0 ** -7 and err[3] < 2.0 ** -15 and err[6] < 2.0 ** -20 and err[6] < err[3] < err[1], err
