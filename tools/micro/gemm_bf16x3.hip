@@ -201,6 +201,97 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const bf16_t* __restrict_
       }
 }
 
+// The direct-to-LDS tile with 32-deep chunks: 64-byte rows, 64 KB of LDS per workgroup -> TWO workgroups per CU (two waves per SIMD, as the library's fp32
+// tiles run): one workgroup's barrier / DMA wait is the other's MFMA stream.  Swizzle for 64-byte rows: 16-byte piece c of row r sits at slot c ^ ((r >> 2) & 3)
+// (rows r, r + 4, r + 8, r + 12 share a 64-byte quarter of the 256-byte bank row).
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_dma32_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
+                                                                                                    float* __restrict__ C, int M, int N, int K) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  typedef __attribute__((address_space(3))) void* lds_t;
+  constexpr int PL = 128 * 64, BUF = 4 * PL;      // plane = 128 rows x 64 bytes
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ntn = N / BN;
+  const int m0 = (blockIdx.x / ntn) * BM, n0 = (blockIdx.x % ntn) * BN;
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(A), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(B), 0, 0x7fffffff, 0x00020000);
+  // wave w, instruction i (2 per plane) -> rows (w * 2 + i) * 16 + (lane >> 2); LDS slot lane & 3 <- source piece slot ^ ((row >> 2) & 3) = slot ^ ((lane >> 4) & 3)
+  unsigned voA[2], voB[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = (wave * 2 + i) * 16 + (lane >> 2);
+    const unsigned c = (unsigned)((lane & 3) ^ ((lane >> 4) & 3));
+    voA[i] = ((unsigned)(m0 + row) * (unsigned)K + c * 8u) * 2u;
+    voB[i] = ((unsigned)(n0 + row) * (unsigned)K + c * 8u) * 2u;
+  }
+  const unsigned plA = (unsigned)M * (unsigned)K * 2u, plB = (unsigned)N * (unsigned)K * 2u;
+  auto issue = [&](int buf, int k0) {
+    unsigned char* d = smem + buf * BUF + wave * 2 * 1024;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_t)(d + p * PL + i * 1024), 16, voA[i], (unsigned)p * plA + (unsigned)k0 * 2u, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_t)(d + (2 + p) * PL + i * 1024), 16, voB[i], (unsigned)p * plB + (unsigned)k0 * 2u, 0, 0);
+    }
+  };
+  f16v acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int fr = lane & 31, kg = lane >> 5;
+  auto mma = [&](int buf) {
+    const unsigned char* s = smem + buf * BUF;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf8 fa[2][2], fb[2][2];
+      const int c = ks * 2 + kg;
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int ra = wm * 64 + i * 32 + fr, rb = wn * 64 + i * 32 + fr;
+          fa[p][i] = *reinterpret_cast<const bf8*>(s + p * PL + ra * 64 + ((c ^ ((ra >> 2) & 3)) << 4));
+          fb[p][i] = *reinterpret_cast<const bf8*>(s + (2 + p) * PL + rb * 64 + ((c ^ ((rb >> 2) & 3)) << 4));
+        }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][i], fb[0][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[1][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[0][j], acc[i][j], 0, 0, 0);
+        }
+    }
+  };
+  const int nk = K / 32;
+  issue(0, 0);
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  for (int kc = 0; kc + 1 < nk; ++kc) {
+    const int buf = kc & 1;
+    issue(buf ^ 1, (kc + 1) * 32);
+    mma(buf);
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+  }
+  mma((nk - 1) & 1);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg, col = n0 + wn * 64 + j * 32 + fr;
+        C[(size_t)row * N + col] = acc[i][j][r];
+      }
+}
+
 static bf16_t bf16_rne(float x) {
   unsigned u;
   memcpy(&u, &x, 4);
@@ -289,10 +380,15 @@ static void time_split(size_t n) {
   (void)hipFree(o);
 }
 
-static bool g_dma = false;      // the direct-to-LDS variant (two planes per operand only)
+static int g_dma = 0;      // 1: the direct-to-LDS variant (two planes per operand only); 2: + 32-deep chunks, two workgroups per CU
 template <int PARTS>
 static void launch(const bf16_t* A, const bf16_t* B, float* C, int M, int N, int K) {
   const int lds = (PARTS == 2 ? 2 : 1) * 2 * PARTS * PLANE, grid = (M / BM) * (N / BN);
+  if (g_dma == 2 && PARTS == 2) {
+    (void)hipFuncSetAttribute((const void*)gemm_dma32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    gemm_dma32_kernel<<<grid, 256, 64 * 1024>>>(A, B, C, M, N, K);
+    return;
+  }
   if (g_dma && PARTS == 2) {
     (void)hipFuncSetAttribute((const void*)gemm_dma_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     gemm_dma_kernel<2><<<grid, 256, lds>>>(A, B, C, M, N, K);
@@ -338,7 +434,7 @@ static void check(int M, int N, int K) {
       worst = fmax(worst, fabs(hC[(size_t)i * N + j] - s) / sa);
       worst32 = fmax(worst32, fabs((double)s32 - s) / sa);
     }
-  printf("check%s %d x %d x %d, %d products: worst |C - exact| / sum|a b| = %.3e  [host fp32 fma chain %.3e]\n", g_dma && PARTS == 2 ? " (direct-to-LDS)" : "", M, N, K, PARTS == 3 ? 6 : 3, worst, worst32);
+  printf("check%s %d x %d x %d, %d products: worst |C - exact| / sum|a b| = %.3e  [host fp32 fma chain %.3e]\n", g_dma && PARTS == 2 ? (g_dma == 2 ? " (direct-to-LDS, BK 32, 2 WG/CU)" : " (direct-to-LDS)") : "", M, N, K, PARTS == 3 ? 6 : 3, worst, worst32);
   (void)hipFree(A);
   (void)hipFree(B);
   (void)hipFree(C);
@@ -371,7 +467,7 @@ static void timeit(int M, int N, int K) {
   (void)hipEventElapsedTime(&ms, e0, e1);
   ms /= reps;
   const double flop = 2.0 * M * N * K;
-  printf("time%s  %6d x %5d x %5d, %d products, %5d workgroups: %8.1f us  %6.1f fp32-equivalent TFLOP/s  (%7.1f bf16 TFLOP/s)\n", g_dma && PARTS == 2 ? " (direct-to-LDS)" : "", M, N, K, PARTS == 3 ? 6 : 3,
+  printf("time%s  %6d x %5d x %5d, %d products, %5d workgroups: %8.1f us  %6.1f fp32-equivalent TFLOP/s  (%7.1f bf16 TFLOP/s)\n", g_dma && PARTS == 2 ? (g_dma == 2 ? " (direct-to-LDS, BK 32, 2 WG/CU)" : " (direct-to-LDS)") : "", M, N, K, PARTS == 3 ? 6 : 3,
          (M / BM) * (N / BN), ms * 1e3, flop / ms * 1e-9, flop * (PARTS == 3 ? 6 : 3) / ms * 1e-9);
   (void)hipFree(A);
   (void)hipFree(B);
@@ -390,13 +486,19 @@ int main() {
   timeit<3>(65536, 256, 2048);
   timeit<3>(15360, 512, 8192);
   timeit<3>(8192, 8192, 4096);
-  g_dma = true;
+  g_dma = 1;
   check<2>(256, 384, 512);
   timeit<2>(65536, 256, 2048);
   timeit<2>(16384, 512, 4096);
   timeit<2>(15360, 512, 8192);
   timeit<2>(8192, 8192, 4096);
-  g_dma = false;
+  g_dma = 2;
+  check<2>(256, 384, 512);
+  timeit<2>(65536, 256, 2048);
+  timeit<2>(16384, 512, 4096);
+  timeit<2>(15360, 512, 8192);
+  timeit<2>(8192, 8192, 4096);
+  g_dma = 0;
   time_split<2>((size_t)16 * 128 * 128 * 128);      // PatchGAN layer-2 input at batch 16 (134 MB)
   time_split<3>((size_t)16 * 128 * 128 * 128);
   time_split<2>((size_t)16 * 32 * 32 * 512);          // layer-4 input (33 MB)
