@@ -6,7 +6,7 @@ decision to build one rests on numbers: the oracle's C2 headline step (256 x 256
 run in fp64, in fp32, and in fp32 with the discriminator's three 128/256/512-channel 4x4 convolutions -- forward, data gradient and weight
 gradient -- replaced by the split form (each bf16 x bf16 product is exact in fp32, so fp32 convolutions of the split operands ARE the
 arithmetic of the matrix pipe up to summation order).  Printed in the units of tests/test_spade_gpu.py::check_grads.
-    python tools/bf16x3_numerics.py [size] [batch] [terms] [which] [c2 | c3]      terms: 1 | 2 | 3 (default) | 4 | 6, see combine(); which: subset of 'fdw' (the discriminator's wide layers: forward / dgrad / wgrad; 'F' = forward with 6 terms whatever [terms] says) and 't' (every dense conv of the frozen teacher)"""
+    python tools/bf16x3_numerics.py [size] [batch] [terms] [which] [c2 | c3 | c4]      terms: 1 | 2 | 3 (default) | 4 | 6, see combine(); which: subset of 'fdw' (the discriminator's wide layers: forward / dgrad / wgrad; 'F' = forward with 6 terms whatever [terms] says) and 't' (every dense conv of the frozen teacher)"""
 import os
 import sys
 
@@ -20,6 +20,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tools'))
 TERMS = 3
 WHICH = 'fdw'      # which of forward / data gradient / weight gradient use the split form
+SPADE = False
 
 
 def split(t, parts=2):
@@ -54,21 +55,22 @@ def combine(fn, a, b, terms=None):
 
 class SplitConv(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, stride, padding):
+    def forward(ctx, x, w, stride, padding, which=None):
+        which = WHICH if which is None else which
         ctx.save_for_backward(x, w)
-        ctx.geom = (stride, padding)
+        ctx.geom = (stride, padding, which)
         fn = lambda a, b: _conv(a, b, None, stride, padding)
-        return combine(fn, x, w, 6) if 'F' in WHICH else (combine(fn, x, w) if 'f' in WHICH else fn(x, w))
+        return combine(fn, x, w, 6) if 'F' in which else (combine(fn, x, w) if 'f' in which else fn(x, w))
 
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
-        stride, padding = ctx.geom
+        stride, padding, which = ctx.geom
         fd = lambda a, b: G.conv2d_input(x.shape, b, a, stride, padding)
         fw = lambda a, b: G.conv2d_weight(b, w.shape, a, stride, padding)
-        dx = (combine(fd, dy, w) if 'd' in WHICH else fd(dy, w)) if ctx.needs_input_grad[0] else None
-        dw = (combine(fw, dy, x) if 'w' in WHICH else fw(dy, x)) if ctx.needs_input_grad[1] else None
-        return dx, dw, None, None
+        dx = (combine(fd, dy, w) if 'd' in which else fd(dy, w)) if ctx.needs_input_grad[0] else None
+        dw = (combine(fw, dy, x) if 'w' in which else fw(dy, x)) if ctx.needs_input_grad[1] else None
+        return dx, dw, None, None, None
 
 
 _conv = F.conv2d
@@ -77,7 +79,17 @@ STATS = {'calls': 0}
 
 def patched_conv2d(x, w, b=None, stride=1, padding=0, dilation=1, groups=1):
     # the layers the library runs on the three direct-to-LDS wide tiles (csrc/conv_igemm.hip: fwd_bk32_ok / dgrad32d_ok / wgrad32d_nsplit)
-    wide = x.dtype == torch.float32 and groups == 1 and dilation in (1, (1, 1)) and w.shape[2:] == (4, 4) and w.shape[1] % 128 == 0 and w.shape[0] > 96
+    dense = x.dtype == torch.float32 and groups == 1 and dilation in (1, (1, 1))
+    if SPADE and dense:      # GauGAN: the eligibility rules themselves (VGG19's and the discriminators' layers; each direction on its own rule)
+        co, ci = w.shape[0], w.shape[1]
+        el = ('f' if ci % 16 == 0 and ci >= 64 and co >= 32 else '') + ('d' if ci > 96 and co % 32 == 0 else '') + ('w' if co > 96 and ci % 128 == 0 else '')
+        use = ''.join(c for c in el if c in WHICH or (c == 'f' and 'F' in WHICH))
+        if not use:
+            return _conv(x, w, b, stride, padding, dilation, groups)
+        STATS['calls'] += 1
+        y = SplitConv.apply(x, w, stride, padding, use + ('F' if 'F' in WHICH and 'f' in el else ''))
+        return y if b is None else y + b.view(1, -1, 1, 1)
+    wide = dense and w.shape[2:] == (4, 4) and w.shape[1] % 128 == 0 and w.shape[0] > 96
     if 't' in WHICH and not torch.is_grad_enabled() and x.dtype == torch.float32 and groups == 1 and w.shape[1] >= 16:
         # the frozen teacher's dense convolutions (distill_step runs it under no_grad): forward only, nothing is differentiated through it
         STATS['teacher'] = STATS.get('teacher', 0) + 1
@@ -108,7 +120,7 @@ def report(name, got, ref64, own32=None):
 
 
 def main():
-    global TERMS, WHICH
+    global TERMS, WHICH, SPADE
     from oracle import detfill, ref_cpu
     from oracle_fp64_calibration import oracle_cfg, state_dicts, to64
     size = int(sys.argv[1]) if len(sys.argv) > 1 else 256
@@ -116,6 +128,8 @@ def main():
     TERMS = int(sys.argv[3]) if len(sys.argv) > 3 else 3
     WHICH = sys.argv[4] if len(sys.argv) > 4 else 'fdw'
     which = sys.argv[5] if len(sys.argv) > 5 else 'c2'
+    if which == 'c4':
+        return main_spade(nb)
     opt, T, S, D = state_dicts(which)
     cfg = oracle_cfg(opt)
     A, B = detfill.images((nb, 3, size, size), 71), detfill.images((nb, 3, size, size), 72)
@@ -132,6 +146,41 @@ def main():
     print(which.upper() + ' step @%dx%d batch %d; %d discriminator convolutions (x3: forward, dgrad, wgrad) in %d-term split-bf16 arithmetic, applied to [%s]; teacher convolutions in split form: %d' % (size, size, nb, STATS['calls'], TERMS, WHICH, STATS.get('teacher', 0)))
     for k in st64.losses:
         r = abs(st64.losses[k]) + 1e-30
+        print('  loss %-11s fp64 %+.8f   split: %.2e   plain fp32: %.2e   (relative)' % (k, st64.losses[k], abs(stx.losses[k] - st64.losses[k]) / r, abs(st32.losses[k] - st64.losses[k]) / r))
+    for k in ('Sfake_B', 'Tfake_B'):
+        r64 = getattr(st64, k)
+        print('  image %-8s max |d| / max |ref|:  split %.2e   plain fp32 %.2e' % (k, float((getattr(stx, k).double() - r64).abs().max() / r64.abs().max()),
+                                                                                float((getattr(st32, k).double() - r64).abs().max() / r64.abs().max())))
+    report('  student gradients', stx.grads_S, st64.grads_S, st32.grads_S)
+    report('  discriminator gradients', stx.grads_D, st64.grads_D, st32.grads_D)
+
+
+def main_spade(nb):
+    """The GauGAN step (BASELINE configs[3], 512 x 256): VGG19's and the two discriminators' wide layers in split form."""
+    global SPADE
+    from oracle import detfill, ref_spade_cpu as R
+    from oracle_fp64_calibration import spade_state_dicts, to64
+    SPADE = True
+    opt, cfg, T, S, D, V = spade_state_dicts()
+    h, w = 256, 512
+    rng = np.random.default_rng(5)
+    lab = torch.from_numpy(np.repeat(np.repeat(rng.integers(0, 35, (nb, 1, h // 16, w // 16)), 16, 2), 16, 3))
+    ins = torch.from_numpy(np.repeat(np.repeat(rng.integers(0, 1000, (nb, 1, h // 16, w // 16)), 16, 2), 16, 3).astype(np.int32))
+    img = detfill.images((nb, 3, h, w), 6)
+    sem = R.preprocess_input(lab, ins, 35)
+    st64 = R.SpadeState(to64(T), to64(S), to64(D), to64(V), cfg)
+    R.spade_step(st64, sem.double(), img.double())
+    st32 = R.SpadeState(T, S, D, V, cfg)
+    R.spade_step(st32, sem, img)
+    stx = R.SpadeState(T, S, D, V, cfg)
+    F.conv2d = patched_conv2d
+    try:
+        R.spade_step(stx, sem, img)
+    finally:
+        F.conv2d = _conv
+    print('C4 (GauGAN) step @512x256 batch %d; %d convolution calls in %d-term split-bf16 arithmetic, directions [%s] where the layer is eligible' % (nb, STATS['calls'], TERMS, WHICH))
+    for k in st64.losses:
+        r = max(abs(st64.losses[k]), 1e-2)
         print('  loss %-11s fp64 %+.8f   split: %.2e   plain fp32: %.2e   (relative)' % (k, st64.losses[k], abs(stx.losses[k] - st64.losses[k]) / r, abs(st32.losses[k] - st64.losses[k]) / r))
     for k in ('Sfake_B', 'Tfake_B'):
         r64 = getattr(st64, k)

@@ -41,6 +41,34 @@ def state_dicts(which='c2'):
     return opt, cpu(T), cpu(S), cpu(D)
 
 
+def spade_state_dicts(size=256, target_flops=5.6e9):
+    """bench.py's GauGAN model (BASELINE configs[3]) built on the host: teacher ngf 64 with the canonical fill, the student architecture
+    shrink_spade_model searches for `target_flops` (fresh initialisation, as the reference leaves it), multiscale SN-PatchGAN ndf 64, VGG19 with
+    random weights of the real topology.  Returns (opt, cfg for oracle/ref_spade_cpu.SpadeState, teacher, student, D, VGG state dicts)."""
+    import argparse
+    from cat_amd import prune, synthetic
+    from cat_amd.spade_modules import SPADEDistillerModules
+    opt = synthetic.default_options(norm='instance', gpu_ids=[])
+    opt.__dict__.update(dict(
+        distiller='spade', input_nc=35, output_nc=3, semantic_nc=36, contain_dontcare_label=False, no_instance=False,
+        teacher_ngf=64, student_ngf=48, pretrained_ngf=64, teacher_netG='inception_spade', student_netG='inception_spade',
+        pretrained_netG='inception_spade', teacher_norm_G='spadesyncbatch3x3', student_norm_G='spadesyncbatch3x3',
+        pretrained_norm_G='spadesyncbatch3x3', num_upsampling_layers='more', crop_size=2 * size, aspect_ratio=2.0,
+        netD='multi_scale', ndf=64, n_layers_D=4, num_D=2, norm_D='spectralinstance', init_type='xavier', init_gain=0.02,
+        gan_mode='hinge', lambda_gan=1.0, lambda_feat=10.0, lambda_vgg=10.0, lambda_distill=0.5, distill_G_loss_type='ka',
+        no_TTUR=False, lr=2e-4, beta1=0.5, beta2=0.999, target_flops=target_flops, prune_cin_lb=16,
+        data_height=256, data_width=512, data_channel=36, restore_pretrained_G_path=None))
+    torch.manual_seed(233)
+    m = SPADEDistillerModules(argparse.Namespace(**vars(opt)))
+    m.netG_teacher.load_state_dict(synthetic.fill_state_dict(m.netG_teacher.state_dict(), synthetic.SEED_TEACHER_SPADE, gamma_abs_normal=True))
+    _, _, student, _ = prune.spade_search(m.netG_teacher, target_flops, opt)
+    cpu = lambda net: {k: v.detach().clone() for k, v in net.state_dict().items()}
+    vsd = {k.split('.', 1)[1]: v for k, v in cpu(m.criterionVGG.vgg).items()}
+    cfg = dict(G=dict(crop_size=opt.crop_size, aspect_ratio=opt.aspect_ratio, num_upsampling_layers=opt.num_upsampling_layers), num_D=2, n_layers_D=4,
+               lambda_gan=1.0, lambda_feat=10.0, lambda_vgg=10.0, lambda_distill=0.5, lr=opt.lr, beta1=0.5, beta2=0.999, no_TTUR=False)
+    return opt, cfg, cpu(m.netG_teacher), cpu(student), cpu(m.netD), vsd
+
+
 def c2_state_dicts():
     return state_dicts('c2')
 
