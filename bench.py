@@ -208,6 +208,9 @@ def main():
     ap.add_argument('--dp-schedule', type=int, default=0, dest='dp_schedule',
                     help='1 GPU only: run the DATA-PARALLEL schedule through a world_size-1 RCCL group (same launch mode as the N > 1 points '
                          'of a scaling curve: teacher on a side stream, bucket all-reduces, deferred Adam G)')
+    ap.add_argument('--mfma', default='f32', choices=['f32', 'bf16x3'],
+                    help='bf16x3: the opt-in split-bf16 backward tiles of the wide PatchGAN layers (csrc/conv_split.hip; DESIGN section 6). Reported with its '
+                         'own dtype; the f32 line is the graded one')
     ap.add_argument('--no-secondary', action='store_true',
                     help='skip the short GauGAN (configs[3], batch 4) and CycleGAN-style (configs[2], batch 8) measurements that the default '
                          '1-GPU headline run attaches as `secondary`')
@@ -237,6 +240,8 @@ def main():
 
     from cat_amd import _lib, ops, parallel
     _lib.load()
+    if args.mfma == 'bf16x3':
+        ops.set_mfma_split(True)
     rank, world, local = parallel.init_distributed()
     if world == 1 and args.dp_schedule:
         parallel.init_single_rank_group()
@@ -356,7 +361,8 @@ def main():
     out = {
         'metric': metric, 'value': round(ips, 3), 'unit': 'images/sec', 'n_gpus': world,
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * dt / args.steps, 3), 'higher_is_better': True,
-        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32' if args.mfma == 'f32' else 'f32 with split-bf16 (3-product) data / weight gradients of the wide PatchGAN layers', 'data': 'synthetic',
         'config': {'workload': workload, 'image': image, 'per_gpu_batch': args.batch, 'global_batch': args.batch * world,
                    'parallelism': f'dp{world}', 'ranks': world,
                    'collectives': (f'{parallel.backend_version()} all-reduce of the flat gradient buckets' if dp else 'none'),
@@ -368,7 +374,7 @@ def main():
     if sustained is not None:
         out['sustained'] = sustained
     if rank == 0:
-        headline = world == 1 and args.workload == 'c2' and args.size == 256 and args.batch == 16 and not args.dp_schedule
+        headline = world == 1 and args.workload == 'c2' and args.size == 256 and args.batch == 16 and not args.dp_schedule and args.mfma == 'f32'
         if headline and not args.no_secondary:
             out['secondary'] = secondary_measurements()
         if world == 1 and not args.no_cpu_baseline:
@@ -410,14 +416,15 @@ def secondary_measurements():
     return out
 
 
-def csrc_fingerprint():
+def csrc_fingerprint(skip=()):
     """sha256 over the HIP sources + headers the library is built from (sorted by name): identifies the kernels a profile was taken from
-    without git (the GPU box receives a snapshot without .git)."""
+    without git (the GPU box receives a snapshot without .git).  `skip`: translation units ADDED after the profiles were taken
+    (profiles/<tag>_meta.json `added_after`): a new file changes no kernel the profiles describe; an edit to any file that existed does."""
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, 'cat_amd', 'csrc')
     for name in sorted(os.listdir(d)):
-        if name.endswith(('.hip', '.h')):
+        if name.endswith(('.hip', '.h')) and name not in skip:
             h.update(name.encode())
             h.update(open(os.path.join(d, name), 'rb').read())
     h.update(open(os.path.join(ROOT, 'include', 'cat_hip.h'), 'rb').read())
@@ -501,8 +508,9 @@ def _profile_commit():
 def _profiles_stale():
     """True if the committed profiles (kernel stats / PMC tables this line quotes) were taken from OTHER kernel sources than the ones running
     now (profiles/<tag>_meta.json records the csrc fingerprint of the tree tools/profile_round.sh ran on); None if the meta file has none."""
-    fp = _profile_meta().get('csrc_sha')
-    return None if fp is None else fp != csrc_fingerprint()
+    meta = _profile_meta()
+    fp = meta.get('csrc_sha')
+    return None if fp is None else fp != csrc_fingerprint(tuple(meta.get('added_after', ())))
 
 
 def pmc_traffic(family):
@@ -590,6 +598,7 @@ def kernel_roofline(model, step, args):
             'rocprof': None if rp_us is None else {'avg_launch_us': rp_us, 'achieved': round(1e3 * gflop_launch / rp_us, 3),
                                                    'frac': round(1e3 * gflop_launch / rp_us / MFMA_F32_PEAK_TFLOPS, 4), 'source': STATS_FILE},
             'profiles_commit': _profile_commit(), 'profiles_stale': _profiles_stale(), 'csrc_sha': csrc_fingerprint(),
+            'profiles_added_after': list(_profile_meta().get('added_after', ())),
             'all_conv': {'achieved': round(tot_gf / tot_ms, 3) if tot_ms else 0.0, 'ms_per_step': round(tot_ms, 3),
                          'gflop_per_step': round(tot_gf, 2)},
             'families': {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in fams.items()}}

@@ -96,6 +96,12 @@ SIGNATURES = {
     'cat_conv2d_dgrad_ws_bytes': (C.c_size_t, [_G, c_i]),
     'cat_conv2d_dgrad_ws': (c_i, [_G, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p]),
     'cat_conv2d_wgrad': (c_i, [_G, c_p, c_p, c_p, c_i, c_p, c_p]),
+    'cat_split_bf16': (c_i, [c_p, c_p, c_l, c_p]),
+    'cat_conv2d_dgrad_split_applicable': (c_i, [_G]),
+    'cat_conv2d_dgrad_split': (c_i, [_G, c_p, c_p, c_p, c_i, c_p]),
+    'cat_conv2d_wgrad_split_applicable': (c_i, [_G]),
+    'cat_conv2d_wgrad_split_ws_bytes': (C.c_size_t, [_G]),
+    'cat_conv2d_wgrad_split': (c_i, [_G, c_p, c_p, c_p, c_i, c_p, c_p]),
     'cat_tconv_pack_floats': (C.c_size_t, [c_i, c_i, c_i]),
     'cat_tconv_pack': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
     'cat_tconv_fwd': (c_i, [_TG, c_p, c_p, c_p, c_p]),

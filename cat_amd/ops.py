@@ -386,6 +386,39 @@ def transposed_filter(weight, wcl, g):
     return buf
 
 
+# ---------------------------------------------------------------------------------------------- opt-in split-bf16 backward tiles
+# CAT_MFMA=bf16x3: the wide 4x4 PatchGAN layers' data / weight gradients on the bf16 matrix pipe in three-product split form (csrc/conv_split.hip;
+# numerically a no-op for the BACKWARD tiles at the parity suite's bars, not for the forward).  Never the default.
+_MFMA_SPLIT = os.environ.get('CAT_MFMA', '') == 'bf16x3'
+
+
+def set_mfma_split(on):
+    global _MFMA_SPLIT
+    old, _MFMA_SPLIT = _MFMA_SPLIT, bool(on)
+    return old
+
+
+def split_planes(t, n=None):
+    """fp32 tensor (dense storage of n floats, n % 4 == 0) -> its two bf16 planes [2][n] (cat_split_bf16)"""
+    n = t.numel() if n is None else n
+    out = torch.empty(2 * n, device=t.device, dtype=torch.bfloat16)
+    L.call('cat_split_bf16', _p(t), _p(out), n, _stream())
+    return out
+
+
+def split_transposed_filter(weight, wcl, g):
+    """bf16 planes of the [Cin][kh][kw][Cout] filter copy, cached like transposed_filter"""
+    wt = transposed_filter(weight, wcl, g)
+    owner = weight if weight is not None else wcl
+    key = owner._cat_wt[0]
+    ent = getattr(owner, '_cat_wtp', None)
+    if ent is not None and ent[0] == key:
+        return ent[1]
+    planes = split_planes(wt)
+    owner._cat_wtp = (key, planes)
+    return planes
+
+
 def _conv_dgrad(g, dy, w, bias, dx, dxcs, dxcw, st, weight=None):
     if L.query('cat_conv2d_dgrad_t_applicable', C.byref(g)) and weight_wcs(w) is not None:
         wt = transposed_filter(weight, w, g)
@@ -440,6 +473,7 @@ class Conv2dFn(torch.autograd.Function):
         g = _conv_geom(n, h, w, cin, xcs, ho, wo, cout, act_cs(dy), kh, kw, stride, pad, pad_mode, wcs=wcs)
         st = _stream()
         dx = dw = db = None
+        dyp = None      # split-bf16 planes of dy, shared by the data and the weight gradient
         if ctx.needs_input_grad[0]:
             tile = tconv_applicable(n, h, w, cin, kh, kw, stride, pad, cout)
             if tile:
@@ -457,13 +491,25 @@ class Conv2dFn(torch.autograd.Function):
                 dx = empty_act(n, cin, h, w, x.device)
                 if tile:
                     tconv.run([tconv.Segment(dy, kh, kh - 1 - pad, False, 0)], pk, None, dx, cin, n, ho, wo, h, w)
+                elif _MFMA_SPLIT and act_cs(dx) == cin and weight_wcs(wcl) is not None and L.query('cat_conv2d_dgrad_split_applicable', C.byref(g)):
+                    dyp = split_planes(dy)
+                    L.call('cat_conv2d_dgrad_split', C.byref(g), _p(dyp), _p(split_transposed_filter(ctx.weight, wcl, g)), _p(dx), act_cs(dx), st)
+                    STATS['split_dgrad'] = STATS.get('split_dgrad', 0) + 1
                 else:
                     _conv_dgrad(g, dy, wcl, None, dx, act_cs(dx), act_cs(dx), st, ctx.weight)
         if ctx.needs_input_grad[1]:
             ws = workspace(L.query('cat_conv2d_wgrad_ws_bytes', C.byref(g)), x.device)
 
             def k(dst, acc):
+                nonlocal dyp
                 gw = _conv_geom(n, h, w, cin, xcs, ho, wo, cout, act_cs(dy), kh, kw, stride, pad, pad_mode, wcs=_grad_wcs(dst))
+                if _MFMA_SPLIT and L.query('cat_conv2d_wgrad_split_applicable', C.byref(gw)):
+                    if dyp is None:
+                        dyp = split_planes(dy)
+                    ws2 = workspace(L.query('cat_conv2d_wgrad_split_ws_bytes', C.byref(gw)), x.device)
+                    L.call('cat_conv2d_wgrad_split', C.byref(gw), _p(split_planes(x)), _p(dyp), _p(dst), acc, _p(ws2), st)
+                    STATS['split_wgrad'] = STATS.get('split_wgrad', 0) + 1
+                    return
                 L.call('cat_conv2d_wgrad', C.byref(gw), _p(x), _p(dy), _p(dst), acc, _p(ws), st)
             dw = _write_param_grad(ctx.weight, k)
         if ctx.bias is not None and ctx.needs_input_grad[2]:

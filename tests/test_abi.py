@@ -8,8 +8,14 @@ from cat_amd import _build, _lib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _headers_text():
+    """cat_hip.h (the default path) + the opt-in headers beside it"""
+    inc = os.path.join(ROOT, 'include')
+    return '\n'.join(open(os.path.join(inc, f)).read() for f in sorted(os.listdir(inc)) if f.endswith('.h'))
+
+
 def _declared():
-    text = open(os.path.join(ROOT, 'include', 'cat_hip.h')).read()
+    text = _headers_text()
     text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
     return sorted(set(re.findall(r'\b(cat_[a-z0-9_]+)\s*\(', text)))
 
@@ -50,7 +56,7 @@ def test_product_does_not_import_the_oracle():
 
 
 def _header_prototypes():
-    text = open(os.path.join(ROOT, 'include', 'cat_hip.h')).read()
+    text = _headers_text()
     text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
     text = re.sub(r'//[^\n]*', '', text)
     protos = {}
