@@ -134,6 +134,15 @@ def cpu_baseline_spade(opt, model, args):
                       f'torch.set_num_threads({cores}) = physical cores of {os.cpu_count()} logical'}
 
 
+# The reference itself cannot travel to the GPU box (it is imported only in the build container).  Timed side by side there
+# (tools/time_reference_cpu.py: this C2 step at batch 2, 256x256, 8 threads, torch 2.10 CPU): the reference's own optimize_parameters
+# 4.02 s/step = 0.50 images/s, this port 2.39 s/step = 0.84 images/s -- the port is the FASTER of the two (no module / hook overhead),
+# so `value` flatters the CPU side by that ratio.
+REFERENCE_VS_PORT = ('kind=port: the reference cannot travel to this box; side by side in the build container (tools/time_reference_cpu.py, batch 2, '
+                     '8 threads) the reference runs 0.50 images/s and this port 0.84 images/s: reference / port = 0.59, i.e. the reference CPU '
+                     'path would read ~0.59 x this value')
+
+
 def physical_cores():
     """Physical cores of the host (time the CPU path on all PHYSICAL cores; 2 x SMT threads oversubscribe ATen's pools:
     the same port ran 0.30 images/s on 128 threads and 0.84 on 8)."""
@@ -178,7 +187,8 @@ def cpu_baseline(opt, model, args):
     dt = sorted(times)[reps // 2]
     return {'value': round(nb / dt, 4), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
             'sample': f'oracle/ref_cpu.distill_step, batch {nb} @ {args.size}x{args.size}, {warm} warm-up + median of {reps} timed steps '
-                      f'({min(times):.2f}-{max(times):.2f} s), torch.set_num_threads({cores}) = physical cores of {os.cpu_count()} logical'}
+                      f'({min(times):.2f}-{max(times):.2f} s), torch.set_num_threads({cores}) = physical cores of {os.cpu_count()} logical. '
+                      + REFERENCE_VS_PORT}
 
 
 def main():
@@ -362,7 +372,7 @@ def main():
         'metric': metric, 'value': round(ips, 3), 'unit': 'images/sec', 'n_gpus': world,
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * dt / args.steps, 3), 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'f32' if args.mfma == 'f32' else 'f32 with split-bf16 (3-product) data / weight gradients of the wide PatchGAN layers', 'data': 'synthetic',
+        'dtype': 'f32' if args.mfma == 'f32' else 'bf16x3', 'data': 'synthetic',
         'config': {'workload': workload, 'image': image, 'per_gpu_batch': args.batch, 'global_batch': args.batch * world,
                    'parallelism': f'dp{world}', 'ranks': world,
                    'collectives': (f'{parallel.backend_version()} all-reduce of the flat gradient buckets' if dp else 'none'),
@@ -384,35 +394,50 @@ def main():
         torch.distributed.destroy_process_group()
 
 
+# child runs of the default 1-GPU headline invocation: (key, extra argv, what it is)
+SECONDARY = (
+    ('spade', ['--workload', 'spade'], 'GauGAN SPADEDistiller, BASELINE configs[3] per GPU: 512x256, batch 4'),
+    ('c3', ['--workload', 'c3'], 'CycleGAN-style InceptionDistiller, BASELINE configs[2] per GPU: batch 8'),
+    ('512x512', ['--size', '512'], 'the headline step at 512x512, batch 16 (north_star asks for both sizes)'),
+    ('c5', ['--batch', '8', '--no-kernel-profile'], 'BASELINE configs[4] per GPU: the headline nets at per-GPU batch 8 (global 64 on 8 GPUs)'),
+    ('dp1', ['--dp-schedule', '1', '--no-kernel-profile'],
+     'the N = 1 point of the scaling curve in the DATA-PARALLEL launch mode: world_size-1 RCCL group, hipGraph segments around the two '
+     'bucket all-reduces, teacher on a side stream, deferred Adam G'),
+    ('bf16x3', ['--mfma', 'bf16x3', '--no-kernel-profile'],
+     'OPT-IN, narrower arithmetic than the reference: split-bf16 (3-product) data / weight gradients of the wide PatchGAN layers; '
+     'never the graded line'),
+)
+
+
 def secondary_measurements():
-    """The two other single-GPU workloads BASELINE.json names, measured by the SAME invocation after the headline's timed region so that they
-    appear in the driver-timed record: GauGAN SPADEDistiller (configs[3] per GPU: 512x256, batch 4) and the CycleGAN-style InceptionDistiller
-    (configs[2] per GPU: batch 8).  Each is a short child run of this script (own process: own caching-allocator pools and hipGraph; 8 timed
-    steps after 3 warm-up steps, the same barrier / synchronize bracket, no CPU baseline) whose JSON line is condensed here.  The headline
-    fields of the parent line are untouched."""
+    """The other single-GPU measurements BASELINE.json / north_star name, taken by the SAME invocation after the headline's timed region so
+    that they appear in the driver-timed record (SECONDARY above).  Each is a short child run of this script (own process: own
+    caching-allocator pools and hipGraph; 8 timed steps after 3 warm-up steps, the same barrier / synchronize bracket, no CPU baseline)
+    whose JSON line is condensed here.  The headline fields of the parent line are untouched."""
     import subprocess
     out = {}
-    for wl in ('spade', 'c3'):
-        cmd = [sys.executable, os.path.abspath(__file__), '--workload', wl, '--steps', '8', '--warmup', '3', '--sustained-steps', '0',
-               '--no-cpu-baseline', '--no-secondary']
+    for key, extra, what in SECONDARY:
+        cmd = [sys.executable, os.path.abspath(__file__)] + extra + ['--steps', '8', '--warmup', '3', '--sustained-steps', '0',
+                                                                     '--no-cpu-baseline', '--no-secondary']
         t0 = time.perf_counter()
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=420)
             line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
             if r.returncode != 0 or not line:
-                out[wl] = {'error': f'rc {r.returncode}: ' + r.stderr[-300:]}
+                out[key] = {'error': f'rc {r.returncode}: ' + r.stderr[-300:]}
                 continue
             j = json.loads(line[-1])
             fams = (j.get('roofline') or {}).get('families') or {}
             sf = j.get('student_forward') or {}
-            out[wl] = {'metric': j['metric'], 'value': j['value'], 'unit': j['unit'], 'ms_per_step': j['ms_per_step'], 'steps': j['steps'],
-                       'per_gpu_batch': j['config']['per_gpu_batch'], 'launch': j['config']['launch'],
-                       'launches_per_step': round(sum(v['launches_per_step'] for v in fams.values()), 1) if fams else None,
-                       'student_forward_ms': sf.get('ms'), 'student_forward_frac_of_fp32_mfma_peak': sf.get('frac_of_fp32_mfma_peak'),
-                       'dominant_kernel': (j.get('roofline') or {}).get('kernel'), 'dominant_frac': (j.get('roofline') or {}).get('frac'),
-                       'wall_s': round(time.perf_counter() - t0, 1)}
+            out[key] = {'what': what, 'metric': j['metric'], 'value': j['value'], 'unit': j['unit'], 'ms_per_step': j['ms_per_step'],
+                        'steps': j['steps'], 'dtype': j['dtype'], 'per_gpu_batch': j['config']['per_gpu_batch'], 'launch': j['config']['launch'],
+                        'schedule': j['config']['schedule'], 'collectives': j['config']['collectives'],
+                        'launches_per_step': round(sum(v['launches_per_step'] for v in fams.values()), 1) if fams else None,
+                        'student_forward_ms': sf.get('ms'), 'student_forward_frac_of_fp32_mfma_peak': sf.get('frac_of_fp32_mfma_peak'),
+                        'dominant_kernel': (j.get('roofline') or {}).get('kernel'), 'dominant_frac': (j.get('roofline') or {}).get('frac'),
+                        'wall_s': round(time.perf_counter() - t0, 1)}
         except Exception as e:      # noqa: BLE001  (a secondary measurement must never cost the headline line)
-            out[wl] = {'error': f'{type(e).__name__}: {e}'}
+            out[key] = {'error': f'{type(e).__name__}: {e}'}
     return out
 
 
