@@ -27,17 +27,22 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
+DIAG_LIB = os.path.join(LIBDIR, 'libcat_hip_diag.so')
+
+
+def build(force=False, verbose=True, diag=False):
+    """diag=True: the DIAGNOSTIC build (-DCAT_DIAG, common.h kDiag) into lib/libcat_hip_diag.so -- per-phase shader clocks and the
+    ablation switches that make results wrong by design; only tools/debug/* load it (CAT_LIB=diag).  Never built by build() / the driver."""
     os.makedirs(LIBDIR, exist_ok=True)
     hdrs = [os.path.join(CSRC, 'common.h'), os.path.join(HERE, '..', 'include', 'cat_hip.h')]
     hipcc = _hipcc()
     objs, jobs = [], []
     for s in SOURCES:
         src = os.path.join(CSRC, s)
-        obj = os.path.join(LIBDIR, s.replace('.hip', '.o'))
+        obj = os.path.join(LIBDIR, s.replace('.hip', '.diag.o' if diag else '.o'))
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):
-            jobs.append([hipcc] + FLAGS + ['-c', src, '-o', obj])
+            jobs.append([hipcc] + FLAGS + (['-DCAT_DIAG'] if diag else []) + ['-c', src, '-o', obj])
 
     def run(cmd):
         if verbose:
@@ -48,10 +53,11 @@ def build(force=False, verbose=True):
 
     with ThreadPoolExecutor(max_workers=min(6, max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))
-    if force or jobs or _stale(LIB, objs):
-        run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs)
-    return LIB
+    lib = DIAG_LIB if diag else LIB
+    if force or jobs or _stale(lib, objs):
+        run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', lib] + objs)
+    return lib
 
 
 if __name__ == '__main__':
-    print(build(force='--force' in sys.argv))
+    print(build(force='--force' in sys.argv, diag='--diag' in sys.argv))

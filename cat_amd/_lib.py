@@ -182,6 +182,11 @@ _lib = None
 
 
 def lib_path():
+    """The production library; CAT_LIB=diag (tools/debug/* only) selects the diagnostic build, whose ablation switches make results wrong."""
+    if os.environ.get('CAT_LIB') == 'diag':
+        import sys
+        print('cat_amd: loading the DIAGNOSTIC library (CAT_LIB=diag): timing experiments only, results may be intentionally wrong', file=sys.stderr)
+        return _build.DIAG_LIB
     return _build.LIB
 
 

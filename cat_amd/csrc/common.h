@@ -9,6 +9,16 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 
 namespace cat {
 
+// Timing diagnostics -- per-phase shader clocks (CAT_DBG), scheduling experiments (CAT_SCHED, CAT_LDS_PAD) and the ablation switches that make
+// results WRONG by design (CAT_PK_ABLATE, CAT_Q_ABLATE) -- exist only in the DIAGNOSTIC build of the library: `python -m cat_amd._build --diag`
+// compiles with -DCAT_DIAG into lib/libcat_hip_diag.so, which tools/debug/* load through CAT_LIB=diag.  In the production library every
+// `kDiag && ...` condition is a compile-time false: the branches and their operands are not in the kernels.
+#ifdef CAT_DIAG
+constexpr bool kDiag = true;
+#else
+constexpr bool kDiag = false;
+#endif
+
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
 

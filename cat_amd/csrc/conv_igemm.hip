@@ -47,8 +47,7 @@ struct IgemmArgs {
   int ksplit, kchunks;
   float* part;
   const float* bt;  // dgrad: filters transposed to [Cin][taps][Cout] (cat_conv2d_dgrad_t), or null
-  int ablate;  // diagnostics only
-  long long* dbg;  // diagnostics only (CAT_DBG): per-phase shader-clock totals of one wave
+  long long* dbg;  // diagnostic build only (cat::kDiag, CAT_DBG): per-phase shader-clock totals of one wave
 };
 
 __device__ __forceinline__ int swz(int r, int q) { return (r * 4 + (q ^ ((r >> 1) & 3))) * 4; }
@@ -215,19 +214,20 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(IgemmArgs p) {
   __syncthreads();
   // steady state: one basic block per chunk (prefetch of chunk kc+1 is unconditional; the last chunk is peeled) so that the
   // scheduler directives below can interleave the gather's address arithmetic / loads with the MFMA stream
-  const bool dbg = p.dbg != nullptr && blockIdx.x == 9 && tid == 0;
+  const bool pdbg = cat::kDiag && p.dbg != nullptr;      // compile-time false in the production library
+  const bool dbg = pdbg && blockIdx.x == 9 && tid == 0;
   long long t_load = 0, t_mma = 0, t_store = 0, t_bar = 0;
   for (int kc = 0; kc + 1 < nk; ++kc) {
     const int buf = kc & 1;
     long long c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0;
-    if (p.dbg) { __builtin_amdgcn_sched_barrier(0); c0 = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
+    if (pdbg) { __builtin_amdgcn_sched_barrier(0); c0 = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
     gload();
-    if (p.dbg) { __builtin_amdgcn_sched_barrier(0); c1 = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
+    if (pdbg) { __builtin_amdgcn_sched_barrier(0); c1 = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
     mma_kcontig_a_kcontig_b<MT, NT>(sA + buf * BM * 16, sB + buf * BN * 16, wm * MT * 16, wn * NT * 16, lane, acc);
     __builtin_amdgcn_sched_barrier(0);   // keep the LDS stores (which wait for the prefetch) behind the MFMA stream
-    if (p.dbg) { c2 = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
+    if (pdbg) { c2 = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
     sstore(buf ^ 1);
-    if (p.dbg) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); c3 = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
+    if (pdbg) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); c3 = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
     if (SCHED == 1) {
 #pragma unroll
       for (int g = 0; g < MT * NT * 4; ++g) {
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(IgemmArgs p) {
       __builtin_amdgcn_iglp_opt(0);
     }
     __syncthreads();
-    if (p.dbg) {
+    if (pdbg) {
       __builtin_amdgcn_sched_barrier(0);
       c4 = __builtin_readcyclecounter();
       t_load += c1 - c0; t_mma += c2 - c1; t_store += c3 - c2; t_bar += c4 - c3;
@@ -1726,7 +1726,8 @@ extern "C" {
 
 static bool fwd_bk32_ok(const IgemmArgs& a) {
   static const int no_bk32 = getenv("CAT_NO_BK32") ? atoi(getenv("CAT_NO_BK32")) : 0;
-  return !no_bk32 && a.wvec && (a.c4 & 15) == 0 && !getenv("CAT_DBG");
+  static const bool dbg_on = cat::kDiag && getenv("CAT_DBG");
+  return !no_bk32 && a.wvec && (a.c4 & 15) == 0 && !dbg_on;
 }
 
 static int fwd_setup(IgemmArgs& a, const cat_conv_t* g) {
@@ -1763,8 +1764,6 @@ static int conv_fwd_impl(const cat_conv_t* g, const float* x, const float* w, co
   IgemmArgs a{};
   if (int e = fwd_setup(a, g)) return e;
   a.a = x; a.b = w; a.bias = bias; a.out = y;
-  static const int ablate = getenv("CAT_ABLATE") ? atoi(getenv("CAT_ABLATE")) : 0;
-  a.ablate = ablate;
   a.cw = g->ycw > g->Cout ? g->ycw : g->Cout;
   CAT_REQUIRE(a.cw <= g->ycs, "conv fwd: ycw > ycs");
   hipStream_t s = (hipStream_t)stream;
@@ -1780,10 +1779,12 @@ static int conv_fwd_impl(const cat_conv_t* g, const float* x, const float* w, co
     return 0;
   }
   const double prof_flops = 2.0 * (double)g->N * g->Ho * g->Wo * g->Cout * g->kh * g->kw * g->Cin;
-  static const int sched = getenv("CAT_SCHED") ? atoi(getenv("CAT_SCHED")) : 0;
-  static const int lds_pad = getenv("CAT_LDS_PAD") ? atoi(getenv("CAT_LDS_PAD")) : 0;  // diagnostics: caps workgroups/CU
+  // diagnostic build only (common.h kDiag): scheduling experiments, an LDS pad that caps workgroups per CU, per-phase shader clocks
+  static const int sched = (cat::kDiag && getenv("CAT_SCHED")) ? atoi(getenv("CAT_SCHED")) : 0;
+  static const int lds_pad = (cat::kDiag && getenv("CAT_LDS_PAD")) ? atoi(getenv("CAT_LDS_PAD")) : 0;
+  static const bool dbg_on = cat::kDiag && getenv("CAT_DBG");
   static long long* dbg_buf = nullptr;
-  if (getenv("CAT_DBG")) {
+  if (dbg_on) {
     if (!dbg_buf) (void)hipMalloc(&dbg_buf, 64);
     (void)hipMemsetAsync(dbg_buf, 0, 64, s);
     a.dbg = dbg_buf;

@@ -37,8 +37,9 @@ struct Launch {
   int hl, tr, tc;          // halo (left / top), staged rows / columns
   int tiles_x, tiles;      // output tiles per row / per image
   int nt_total, nblk;      // 16-wide N tiles of the output, N blocks (gridDim.x = N * tiles * nblk)
-  int ablate;              // diagnostics (CAT_PK_ABLATE, results become wrong): 1 every group reads the SAME filter block (L1 hits), 2 every
-                           // A fragment reads LDS offset 0, 4 staging loads hit one cached line, 8 no staging / barrier after the first chunk
+  int ablate;              // DIAGNOSTIC BUILD ONLY (cat::kDiag; CAT_PK_ABLATE, results become wrong): 1 every group reads the SAME filter block
+                           // (L1 hits), 2 every A fragment reads LDS offset 0, 4 staging loads hit one cached line, 8 no staging / barrier after
+                           // the first chunk.  The production kernels read `abl`, a compile-time 0
 };
 
 __device__ __forceinline__ f4 bload(const __amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff_) {
@@ -120,6 +121,7 @@ __global__ __launch_bounds__(256) void tconv_kernel(const cat_tconv_t g, const f
   const int j0 = nb * NT;
   const int slots = L.tr * L.tc * 4;
   const int quad = tid & 3;
+  const int abl = cat::kDiag ? L.ablate : 0;
 
   // staging map: this thread's patch pixels (independent of the segment)
   int sy[MAXIT], sx[MAXIT];
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(256) void tconv_kernel(const cat_tconv_t g, const f
       smask |= v ? (1u << it) : 0u;
       soff[it] = v ? ((unsigned)(n * g.H + iy) * (unsigned)g.W + (unsigned)ix) * (unsigned)xcs + quad * 4 : 0u;   // < 2^32 elements (host-checked)
     }
-    if (L.ablate & 4) smask = 0;
+    if (abl & 4) smask = 0;
   };
   f4 sreg[MAXIT], ssc, ssh;
   int s_act = 0;
@@ -207,7 +209,7 @@ __global__ __launch_bounds__(256) void tconv_kernel(const cat_tconv_t g, const f
           off = ((d + ky) * L.tc + d + kx) * PITCH + qd * 4;
         }
       }
-      tab0[buf * TABN + tid] = (L.ablate & 2) ? 0 : off;
+      tab0[buf * TABN + tid] = (abl & 2) ? 0 : off;
     }
   };
 
@@ -253,11 +255,11 @@ __global__ __launch_bounds__(256) void tconv_kernel(const cat_tconv_t g, const f
       }
     }
     const bool more = ns < g.nseg;
-    const bool stage = !(L.ablate & 8);
+    const bool stage = !(abl & 8);
     if (more && stage) gload(ns, nc0);   // in flight behind this chunk's MFMA stream
 
-    mma_groups<MT, NT>(acc, tile0 + buf * tile_floats, tab0 + buf * TABN + lq, abase, prsrc, jb, (L.ablate & 1) ? 0u : (unsigned)cpack * 4u,
-                       (L.ablate & 1) ? 0u : (unsigned)gstride * 4u, ngr);
+    mma_groups<MT, NT>(acc, tile0 + buf * tile_floats, tab0 + buf * TABN + lq, abase, prsrc, jb, (abl & 1) ? 0u : (unsigned)cpack * 4u,
+                       (abl & 1) ? 0u : (unsigned)gstride * 4u, ngr);
     if (!more) break;
     if (stage) {
       sstore(buf ^ 1, ns, nc0);
@@ -673,9 +675,9 @@ int cat_tconv_fwd(const cat_tconv_t* g, const float* pack, const float* bias, fl
   const int tw = g->stats ? 16 : (tw_env ? tw_env : (wg16 >= tw32_minwg && nt <= tw32_maxnt ? 32 : 16));
   CAT_REQUIRE(tw == 16 || tw == 32, "tconv: CAT_PK_TW must be 16 or 32");
   CAT_REQUIRE(g->stats == nullptr || (g->act == CAT_ACT_NONE && g->res == nullptr && g->scs >= g->ycw), "tconv: statistics need a plain epilogue");
-  // diagnostic switch (tools/debug/tconv_ablate.py): read ONCE per process, and loud -- a non-zero value makes the results wrong by design
+  // diagnostic build only (tools/debug/tconv_ablate.py): read ONCE per process, and loud -- a non-zero value makes the results wrong by design
   static const int ablate_env = [] {
-    const int v = getenv("CAT_PK_ABLATE") ? atoi(getenv("CAT_PK_ABLATE")) : 0;
+    const int v = (cat::kDiag && getenv("CAT_PK_ABLATE")) ? atoi(getenv("CAT_PK_ABLATE")) : 0;
     if (v) fprintf(stderr, "libcat_hip: CAT_PK_ABLATE=%d -- tconv results are INTENTIONALLY WRONG (timing diagnostics only)\n", v);
     return v;
   }();

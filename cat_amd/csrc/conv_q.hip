@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void qconv_kernel(const KArgs ka) {
   const int tile_floats = P.pr * P.pc * PITCH;
   const int npix = P.pr * P.pc;
   float* tile0 = smem;
-  const int abl = P.ablate;
+  const int abl = cat::kDiag ? P.ablate : 0;      // diagnostic build only; compile-time 0 in the production kernels
 
   // staging map: slot = pixel * NCQ + quad; an iteration covers ACT = (256 / NCQ) * NCQ slots, so a thread keeps ONE channel quad (tid % NCQ)
   // through all its iterations -- the staging affine's scale / shift are two registers per chunk, loaded together with the data (the first
@@ -591,7 +591,7 @@ static int make_plan(const cat_qconv_t* g, Plan* P) {
   P->nbuf = multi ? 2 : 1;
   P->ftab = cat::round_up((total + 2) * 4, 64);      // two spare rows: the kernel requests offsets up to two steps ahead
   static const int ablate_env = [] {
-    const int v = getenv("CAT_Q_ABLATE") ? atoi(getenv("CAT_Q_ABLATE")) : 0;
+    const int v = (cat::kDiag && getenv("CAT_Q_ABLATE")) ? atoi(getenv("CAT_Q_ABLATE")) : 0;
     if (v) fprintf(stderr, "libcat_hip: CAT_Q_ABLATE=%d -- qconv results are INTENTIONALLY WRONG (timing diagnostics only)\n", v);
     return v;
   }();

@@ -192,6 +192,11 @@ class _Plan:
         self.key = None
         self.bkey = None
 
+    def __deepcopy__(self, memo):
+        """A copied module builds its own plan at its first forward (plans hold device buffers, job tables with raw parameter addresses and
+        the group of blocks they are prepared with: none of that belongs to the copy)."""
+        return None
+
     # -- job tables ------------------------------------------------------------------------------------------------------
     def _jobs_to_dev(self, jobs):
         arr = (L.PrepJob * len(jobs))()

@@ -105,6 +105,11 @@ def applicable(res_ops, dw_ops, x, training):
         norms = [b['bn1']] + ([b['bn2']] if dw else [])
         if any(not isinstance(nm, cnn.BatchNorm2d) or nm.training != training or not nm.track_running_stats or nm.momentum is None for nm in norms):
             return False
+        # under a multi-rank reducer the fused stage finalize all-reduces the statistics and uses the clamp(var, eps) formula: that is
+        # SynchronizedBatchNorm2d's arithmetic (sync_batchnorm/batchnorm.py:103-140).  A plain nn.BatchNorm2d (norm_G = 'spadebatch3x3') stays
+        # per-replica in the reference (local statistics, var + eps): such units take the per-layer path, whose BatchNorm2d is never synced
+        if synced and any(not isinstance(nm, cnn.SynchronizedBatchNorm2d) for nm in norms):
+            return False
         # the plan keeps ONE (eps, momentum, activation) for the whole unit and assumes 'same' zero padding everywhere
         if any(float(nm.eps) != float(first['bn1'].eps) or float(nm.momentum) != float(first['bn1'].momentum) for nm in norms):
             return False
@@ -303,6 +308,10 @@ class _Plan:
         self.bwd_arr = self._last_arr
         self.tables_version = getattr(self, 'tables_version', 0) + 1
 
+    def __deepcopy__(self, memo):
+        """A copied module builds its own plan at its first forward (cf. fused_block._Plan.__deepcopy__)."""
+        return None
+
     def _epoch_key(self):
         trainable = any(getattr(q, '_cat_grad_view', None) is not None for q in self.params)
         return (optim.weights_epoch() if trainable else -1, tuple(q._version for q in self.params))
@@ -311,11 +320,12 @@ class _Plan:
         return tuple(q.data_ptr() for q in self.params)
 
     def prepare(self, backward=False):
-        group = getattr(self, 'group', None)
+        gref = getattr(self, 'group', None)      # weak reference to the generator that owns this unit (no cycle through the cached plans)
+        group = gref() if gref is not None else None
         if group is not None and (self.bkey if backward else self.key) != self._epoch_key():
             # the first stale unit of a pass refreshes the operands of EVERY fused unit of the generator in one launch (round 4)
             from . import fused_block
-            fused_block.prepare_plans(units_of(group), group, backward)
+            fused_block.prepare_plans(units_of(group), gref, backward)
         if tuple(q.data_ptr() for q in self.params) != self.ptrs:       # FusedAdam re-housed the parameters: same layout, new addresses
             self._build_jobs()
             self.key = self.bkey = self.scatter_jobs = None
@@ -342,12 +352,17 @@ def units_of(generator):
     return out
 
 
+PLAN_GEN = 0      # bumped whenever a unit plan is (re)built: generators regroup their units' operand preparation when it moves
+
+
 def plan_for(owner, slot, res_ops, dw_ops, cin, cout, x):
+    global PLAN_GEN
     p = getattr(owner, slot, None)
     params = [q for m in list(res_ops) + list(dw_ops) for q in m.parameters()]
     if p is None or p.dev != x.device or p.shapes != tuple(tuple(q.shape) for q in params) or p.ids != tuple(id(q) for q in params):
         p = _Plan(res_ops, dw_ops, cin, cout, x.device)
         setattr(owner, slot, p)
+        PLAN_GEN += 1
     return p
 
 

@@ -46,13 +46,17 @@ class InceptionSPADEGenerator(BaseNetwork):
         return width, round(width / opt.aspect_ratio)
 
     def forward(self, input, mapping_layers=[]):
-        if self.training and '_cat_prep_group' not in self.__dict__:
-            # from the second forward on (the units' plans exist): one operand-preparation launch per pass for all fused units
+        if self.training:
+            # one operand-preparation launch per pass for ALL fused units: their plans are grouped once they exist (second forward) and again
+            # whenever a plan was rebuilt since (fused_spade.PLAN_GEN moves: a reducer's broadcast drops the plans, units become applicable
+            # later) -- a plan without a group would silently fall back to one launch per unit.  The plans hold a weak reference to this module.
             from . import fused_block, fused_spade
-            units = fused_spade.units_of(self)
-            if units:
-                fused_block.prepare_plans(units, self, False)
-                self.__dict__['_cat_prep_group'] = True
+            if self.__dict__.get('_cat_prep_gen') != fused_spade.PLAN_GEN:
+                units = fused_spade.units_of(self)
+                if units:
+                    import weakref
+                    fused_block.prepare_plans(units, weakref.ref(self), False)
+                    self.__dict__['_cat_prep_gen'] = fused_spade.PLAN_GEN
         seg = ops.conform(input)
         ret_acts = {}
 

@@ -265,8 +265,8 @@ class FusedSequential(nn.Sequential):
         while i < n:
             m = mods[i]
             nxt = mods[i + 1] if i + 1 < n else None
-            if isinstance(_inner(x), ops.Normed) and not (isinstance(m, ReflectionPad2d) or _edge_conv(m, nxt, x)):
-                x = _materialized(x)      # nobody but a quad-granule conv consumes a pending norm
+            if isinstance(_inner(x), ops.Normed) and not ((isinstance(m, ReflectionPad2d) and not _hooked(m)) or _edge_conv(m, nxt, x)):
+                x = _materialized(x)      # nobody but a quad-granule conv consumes a pending norm (a hooked pad must see a tensor)
             if _edge_conv(m, nxt, x):
                 # narrow conv -> train-mode norm -> activation of the generator's edge (inception_generator.py:37-56): the conv runs on the
                 # quad-granule kernel with the norm's statistics in its epilogue; in a no-grad forward the normalised tensor is not even
@@ -337,6 +337,8 @@ def _edge_conv(m, nxt, x):
     measured 175 + 105 us against 223 + 108 us for the im2col kernels + 30 us of separate statistics passes, profiles/r04_qconv_layers.txt)"""
     if not _QCONV or not isinstance(m, Conv2d) or not isinstance(nxt, _NORMS) or isinstance(nxt, SynchronizedBatchNorm2d):
         return False
+    if _hooked(m):      # the edge path never calls m.forward: a forward (pre-)hook registered on the conv would silently stop firing
+        return False
     if m.groups != 1 or 'weight_orig' in m._parameters or m.dilation != (1, 1) or m.padding_mode != 'zeros' or m.stride[0] != m.stride[1]:
         return False
     if isinstance(nxt, BatchNorm2d) and not (nxt.training or not nxt.track_running_stats):
@@ -362,7 +364,22 @@ def _edge_conv(m, nxt, x):
     if pad >= min(h, w):
         return False
     ho, wo = (h + 2 * pad - k) // st + 1, (w + 2 * pad - k) // st + 1
-    return n * ((ho + 7) // 8) * ((wo + 15) // 16) >= ops._TCONV_MIN_TILES
+    if n * ((ho + 7) // 8) * ((wo + 15) // 16) < ops._TCONV_MIN_TILES:
+        return False
+    try:      # a geometry the kernel has no plan for (cat_qconv_plan fails) declines HERE: the layer takes the general path
+        _q_layer(m, pad, x.mode if isinstance(x, Padded) else L.PAD_ZERO).plan_for(t)
+    except RuntimeError:
+        return False
+    return True
+
+
+def _q_layer(conv, pad, mode):
+    from . import qconv
+    _to_channels_last_(conv)
+    layer = getattr(conv, '_cat_q', None)
+    if layer is None or layer.weight is not conv.weight or layer.pad != pad or layer.reflect != (mode == L.PAD_REFLECT):
+        layer = conv._cat_q = qconv.Layer('conv', conv.weight, stride=conv.stride[0], pad=pad, reflect=mode == L.PAD_REFLECT)
+    return layer
 
 
 def _conv_norm_q(conv, norm, act_mod, x, lazy):
@@ -370,10 +387,7 @@ def _conv_norm_q(conv, norm, act_mod, x, lazy):
     pad, mode = conv.padding[0], L.PAD_ZERO
     if isinstance(x, Padded):
         x, pad, mode = x.x, x.pad, x.mode
-    _to_channels_last_(conv)
-    layer = getattr(conv, '_cat_q', None)
-    if layer is None or layer.weight is not conv.weight or layer.pad != pad or layer.reflect != (mode == L.PAD_REFLECT):
-        layer = conv._cat_q = qconv.Layer('conv', conv.weight, stride=conv.stride[0], pad=pad, reflect=mode == L.PAD_REFLECT)
+    layer = _q_layer(conv, pad, mode)
     act, slope = _act_code(act_mod)
     inst = isinstance(norm, InstanceNorm2d)
     nmode = L.NORM_INSTANCE if inst else L.NORM_BATCH

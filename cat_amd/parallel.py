@@ -176,6 +176,7 @@ class DataParallelReducer:
                     d.copy_(stage)
                 t.__dict__.pop('_cat_pk', None)        # packed-filter cache of the LDS-tile convs
                 t.__dict__.pop('_cat_wt', None)        # transposed-filter cache of the wide dgrad tiles
+                t.__dict__.pop('_cat_wtp', None)       # ... and its split-bf16 planes (CAT_MFMA=bf16x3), keyed by the same (ptr, version, epoch)
             # the broadcast wrote through .data (no version bump): drop every cache derived from the old values
             for sub in m.modules():
                 for attr in ('_cat_frozen', '_cat_fold', '_cat_fused_plan', '_cat_fused_gb', '_cat_fused_main', '_cat_q'):

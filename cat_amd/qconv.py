@@ -53,6 +53,13 @@ def geometry(segs, n, h, w, ho, wo, nn, ycs, ycw=None, stride=1, ncls=1, act=L.A
     return g
 
 
+def _tile_rule():
+    """The library's mutable tile rule (cat_qconv_min_tiles16: from how many 16-wide tiles a layer takes 4-row pixel groups).  A plan -- tile
+    height, quads per wave, layout of the packed stream, size of the statistics table -- depends on it, and cat_qconv_fwd re-plans from the
+    CURRENT value: cached plans and packed streams are keyed on it, so a runtime change never pairs a stale plan with a new launch."""
+    return int(L.query('cat_qconv_min_tiles16', -1))
+
+
 def plan_of(g):
     p = L.QPlan()
     L.call('cat_qconv_plan', C.byref(g), C.byref(p))
@@ -123,7 +130,7 @@ class Layer:
     def plan_for(self, x):
         """The launch plan for an input of x's shape (tile geometry / entries of the statistics table) without launching."""
         n, c, h, w = x.shape
-        key = (n, h, w, c)
+        key = (n, h, w, c, _tile_rule())
         plan = self._plans.get(key)
         if plan is None:
             nn, ho, wo = self.out_shape(x)
@@ -143,14 +150,14 @@ class Layer:
         lat_h, lat_w = (h, w) if ct else (ho, wo)
         g = geometry(segs, n, h, w, lat_h, lat_w, nn, ops.act_cs(y), stride=1 if ct else self.stride, ncls=4 if ct else 1, act=act, slope=slope,
                      stats=stats, scs=scs)
-        key = (n, h, w, c)
+        key = (n, h, w, c, _tile_rule())
         plan = self._plans.get(key)
         if plan is None:
             plan = self._plans[key] = plan_of(g)
         # packed stream: keyed like ops.packed_filter (version counter, or the optimizer epoch for FusedAdam-owned parameters)
         wcl, wcs = ops.weight_cl(self.weight)
         trainable = getattr(self.weight, '_cat_grad_view', None) is not None
-        sig = (plan.cs, plan.nq, plan.nsplit, int(plan.pack_floats))
+        sig = (plan.cs, plan.nq, plan.nsplit, int(plan.pack_floats), plan.th)
         wkey = (wcl.data_ptr(), wcl._version, optim.weights_epoch() if trainable else -1, sig, key)
         if self._pk is None or self._pk[0] != wkey:
             same_layout = self._pk is not None and self._pk[0][3:] == wkey[3:] and self._pk[1].device == x.device

@@ -133,3 +133,13 @@ def test_qconv_structs_match_their_ctypes_mirrors(tmp_path):
         assert got[(cname, 'size')] == C.sizeof(cls), cname
         for fname, _ in cls._fields_:
             assert got[(cname, fname)] == getattr(cls, fname).offset, (cname, fname)
+
+
+def test_production_library_carries_no_diagnostic_switches():
+    """The ablation switches that make results wrong by design and the per-phase clock probes exist only in the diagnostic build
+    (common.h kDiag, `python -m cat_amd._build --diag`): in the production library their environment reads are compiled out."""
+    from cat_amd import _build
+    blob = open(_build.LIB, 'rb').read()
+    for name in (b'CAT_PK_ABLATE', b'CAT_Q_ABLATE', b'CAT_DBG', b'CAT_SCHED', b'CAT_LDS_PAD', b'CAT_ABLATE'):
+        assert name not in blob, name
+    assert not os.path.basename(_build.DIAG_LIB) == os.path.basename(_build.LIB)

@@ -309,3 +309,49 @@ def test_generator_edge_through_fused_sequential(dev, norm):
                 assert rel(bg.float(), br.float()) < TOL, k
     finally:
         ops.set_tconv_min_tiles(old)
+
+
+def test_hooked_edge_layers_keep_their_hooks(dev):
+    """Forward (pre-)hooks on the generator's edge layers must keep firing with tensor arguments (the distillers tap `down_sampling.9` this way,
+    base_inception_distiller.py:247-264): a hooked conv does not take the quad-granule path (its forward would never be called), a hooked
+    ReflectionPad2d never receives a pending (unwritten) norm.  Output equals the un-hooked run."""
+    from cat_amd import nn as cnn, ops, qconv
+    old = ops.set_tconv_min_tiles(1)
+    try:
+        torch.manual_seed(6)
+
+        def build():
+            return cnn.FusedSequential(cnn.ReflectionPad2d(3), cnn.Conv2d(3, 22, 7, padding=0, bias=False), cnn.BatchNorm2d(22), cnn.ReLU(True),
+                                       cnn.ReflectionPad2d(1), cnn.Conv2d(22, 37, 3, padding=0, bias=False), cnn.BatchNorm2d(37), cnn.ReLU(True),
+                                       cnn.Conv2d(37, 40, 3, stride=2, padding=1, bias=False), cnn.BatchNorm2d(40), cnn.ReLU(True)).to(dev).train()
+        plain = build()
+        sd = {k: v.clone() for k, v in plain.state_dict().items()}
+        x = ops.to_nhwc(_gen(2, 3, 40, 48, seed=31).to(dev))
+        runs = {'n': 0}
+        orig = qconv.Layer.run
+
+        def counting(self, *a, **k):
+            runs['n'] += 1
+            return orig(self, *a, **k)
+        qconv.Layer.run = counting
+        try:
+            with torch.no_grad():
+                y_plain = plain(x)
+            assert runs['n'] == 3
+            for hooked_idx, expect_q in ((5, 2), (4, 3), (8, 2)):      # the second conv; the pad in front of it; the stride-2 conv
+                net = build()
+                net.load_state_dict(sd)
+                seen = []
+                net[hooked_idx].register_forward_pre_hook(lambda m, a: seen.append(('pre', type(a[0]))))
+                net[hooked_idx].register_forward_hook(lambda m, a, o: seen.append(('post', type(o))))
+                runs['n'] = 0
+                with torch.no_grad():
+                    y = net(x)
+                assert [s[0] for s in seen] == ['pre', 'post'], (hooked_idx, seen)
+                assert seen[0][1] is not ops.Normed, (hooked_idx, seen)          # never a pending norm
+                assert runs['n'] == expect_q, (hooked_idx, runs['n'])
+                assert rel(y, y_plain) < TOL, hooked_idx
+        finally:
+            qconv.Layer.run = orig
+    finally:
+        ops.set_tconv_min_tiles(old)

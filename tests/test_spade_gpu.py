@@ -615,6 +615,75 @@ def test_fused_spade_units_match_general_path(fin, fout, channels, owned):
     assert rel(y1, y2) < 2e-5
 
 
+def test_plain_batchnorm_units_stay_per_replica_under_a_reducer():
+    """norm_G = 'spadebatch3x3' builds nn.BatchNorm2d in the main unit (reference inception_modules.py:418-419), which DataParallel keeps PER
+    REPLICA: local statistics, var + eps.  With a multi-rank reducer installed (base_spade_distiller does that unconditionally under DP) such a
+    unit must not take the fused path -- whose stage finalize all-reduces the statistics and applies SynchronizedBatchNorm's clamp formula --
+    and its norms must not exchange anything: the six branches give the same output, gradients and running statistics as without a reducer,
+    bit for bit.  (The gamma|beta net of its SPADE layer is SynchronizedBatchNorm2d in every configuration, reference :598, and does
+    exchange.)  The same block built with 'spadesyncbatch3x3' fuses and exchanges: the positive control."""
+    import copy
+    from cat_amd import fused_spade, ops
+    from cat_amd.inception_modules import SPADEInvertedResidualChannels
+    g, opt, lab, ins, img, sds, cfg = fixture()
+
+    class TwoIdenticalRanks:      # what ops.set_bn_sync expects of parallel.DataParallelReducer; the other rank holds the same shard
+        world_size = 2
+        calls = 0
+
+        def all_reduce_sum_(self, t):
+            TwoIdenticalRanks.calls += 1
+            return t.mul_(2.0)
+    n, h, w, fin, fout = 2, 24, 40, 40, 16
+    x = detfill.normal((n, fin, h, w), 600)
+    gy = detfill.normal((n, fout, h, w), 414)
+    res = {}
+    old = ops.set_tconv_min_tiles(1)
+    try:
+        for norm_g in ('spadebatch3x3', 'spadesyncbatch3x3'):
+            o = Namespace(**vars(opt))
+            o.norm_G, o.channels = norm_g, [30, 6, 12]
+            blk = SPADEInvertedResidualChannels(fin, fout, o)
+            blk.load_state_dict(detfill.fill_state_dict(blk.state_dict(), 411, gamma_abs_normal=True))
+            blk = blk.to(dev()).train()
+            seg = (detfill.normal((n, o.semantic_nc, h // 4, w // 4), 413) > 0.8).float().repeat_interleave(4, 2).repeat_interleave(4, 3)
+            for synced in (False, True):
+                net = copy.deepcopy(blk)
+                ops.set_bn_sync(TwoIdenticalRanks() if synced else None)
+                try:
+                    xa = nhwc(x).detach().requires_grad_(True)
+                    fused = fused_spade.applicable(net.res_ops, net.dw_ops, xa, True)
+                    # the six branches alone, layer by layer (what the block runs when the unit is not fused)
+                    TwoIdenticalRanks.calls = 0
+                    branches = [op(xa) for op in list(net.res_ops) + list(net.dw_ops)]
+                    torch.autograd.backward(branches, [nhwc(gy) for _ in branches])
+                    torch.cuda.synchronize()
+                    branch_calls = TwoIdenticalRanks.calls
+                    out = (fused, branch_calls, [t.detach().clone() for t in branches], xa.grad.clone(),
+                           {k: q.grad.clone() for k, q in net.named_parameters() if q.grad is not None},
+                           {k: b_.clone() for k, b_ in net.named_buffers()})
+                    # the whole block through its own dispatch
+                    net2 = copy.deepcopy(blk)
+                    TwoIdenticalRanks.calls = 0
+                    y = net2(nhwc(x).detach().requires_grad_(True), nhwc(seg))
+                    y.backward(nhwc(gy))
+                    torch.cuda.synchronize()
+                    res[norm_g, synced] = out + (getattr(net2, '_cat_fused_main', None) is not None, TwoIdenticalRanks.calls)
+                finally:
+                    ops.set_bn_sync(None)
+    finally:
+        ops.set_tconv_min_tiles(old)
+    fused, calls, y1, dx1, g1, b1, took_fused, _ = res['spadebatch3x3', True]
+    fused0, _, y0, dx0, g0, b0, took_fused0, _ = res['spadebatch3x3', False]
+    assert fused0 and took_fused0                          # one rank: the fused unit serves plain BatchNorm2d (local statistics)
+    assert not fused and not took_fused and calls == 0, (fused, took_fused, calls)
+    assert all(torch.equal(a_, b_) for a_, b_ in zip(y1, y0)) and torch.equal(dx1, dx0)
+    assert g1.keys() == g0.keys() and all(torch.equal(g1[k], g0[k]) for k in g0)
+    assert all(torch.equal(b1[k], b0[k]) for k in b0)
+    fused, calls, _, _, _, _, took_fused, block_calls = res['spadesyncbatch3x3', True]
+    assert fused and took_fused and calls > 0 and block_calls > 0, (fused, took_fused, calls, block_calls)
+
+
 @pytest.mark.parametrize('fin,fout', [(48, 24), (24, 24)])
 def test_fused_spade_units_frozen_match_general_path(fin, fout):
     """The frozen (eval, no-grad) form of the fused SPADE units -- the teacher's blocks: running statistics folded into the consumers' staging,

@@ -5,6 +5,8 @@ L1), 2 = every A fragment reads LDS offset 0 (no bank conflicts), 4 = staging lo
 import os
 import sys
 
+os.environ.setdefault('CAT_LIB', 'diag')      # the ablation switches exist only in the diagnostic build: python -m cat_amd._build --diag
+
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
