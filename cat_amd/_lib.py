@@ -92,6 +92,10 @@ SIGNATURES = {
     'cat_conv2d_dgrad_t': (c_i, [_G, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p]),
     'cat_conv2d_wgrad_ws_bytes': (C.c_size_t, [_G]),
     'cat_conv2d_fwd_ws_bytes': (C.c_size_t, [_G]),
+    'cat_conv2d_fwd_rect': (c_i, [_G, c_i, c_p, c_p, c_p, c_p, c_p]),
+    'cat_pool2d_fwd': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_p]),
+    'cat_global_avgpool_fwd': (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p]),
+    'cat_resize_bilinear_fwd': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_f, c_f, c_p]),
     'cat_conv2d_fwd_ws': (c_i, [_G, c_p, c_p, c_p, c_p, c_p, c_p]),
     'cat_conv2d_dgrad_ws_bytes': (C.c_size_t, [_G, c_i]),
     'cat_conv2d_dgrad_ws': (c_i, [_G, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p]),

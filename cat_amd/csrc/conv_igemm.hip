@@ -29,6 +29,7 @@ struct IgemmArgs {
   int N, H, W, Cin, xcs;
   int Ho, Wo, Cout, ycs;
   int kh, kw, stride, pad, reflect;
+  int padw;      // forward only: implicit padding along W (== pad except through cat_conv2d_fwd_rect: 1 x 7 / 7 x 1 / 1 x 3 / 3 x 1 filters)
   int act;
   float slope;
   int cw;        // channels [Cvalid, cw) of the output pixel get zeros
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(IgemmArgs p) {
     const int n = mm / HoWo, rem = mm - n * HoWo;
     const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
     iy0[i] = oy * p.stride - p.pad;
-    ix0[i] = ox * p.stride - p.pad;
+    ix0[i] = ox * p.stride - p.padw;
     xoff[i] = (int64_t)n * p.H * p.W * p.xcs;
   }
   const float* wrow[BI];
@@ -303,7 +304,7 @@ __global__ __launch_bounds__(256) void conv_fwd32_kernel(IgemmArgs p) {
     const int n = mm / HoWo, rem = mm - n * HoWo;
     const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
     iy0[i] = oy * p.stride - p.pad;
-    ix0[i] = ox * p.stride - p.pad;
+    ix0[i] = ox * p.stride - p.padw;
     xoff[i] = (int64_t)n * p.H * p.W * p.xcs;
   }
   const int nk_all = (p.K + 31) >> 5;   // a trailing half chunk reads zeros (tap >= taps)
@@ -502,7 +503,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int n = mm / HoWo, rem = mm - n * HoWo;
     const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
     iy0[i] = oy * p.stride - p.pad;
-    ix0[i] = ox * p.stride - p.pad;
+    ix0[i] = ox * p.stride - p.padw;
     abase[i] = (unsigned)n * (unsigned)(p.H * p.W) * (unsigned)p.xcs * 4u;
     aq[i] = q * 16u;
     const int co = n0 + row;
@@ -1669,17 +1670,18 @@ static int reduce_grid(int64_t n) {
   return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
 }
 
-int fill_common(IgemmArgs& a, const cat_conv_t* g) {
+int fill_common(IgemmArgs& a, const cat_conv_t* g, int pad_w = -1) {
+  const int padw = pad_w >= 0 ? pad_w : g->pad;
   CAT_REQUIRE(g->N > 0 && g->H > 0 && g->W > 0 && g->Cin > 0 && g->Cout > 0, "conv: empty geometry");
   CAT_REQUIRE(g->stride == 1 || g->stride == 2, "conv: stride %d unsupported", g->stride);
   CAT_REQUIRE(g->xcs % 4 == 0 && g->ycs % 4 == 0, "conv: pixel strides must be multiples of 4 (xcs=%d ycs=%d)", g->xcs, g->ycs);
   CAT_REQUIRE(g->xcs >= ((g->Cin + 3) & ~3) && g->ycs >= ((g->Cout + 3) & ~3), "conv: pixel stride smaller than padded channel count");
-  CAT_REQUIRE(g->Ho == (g->H + 2 * g->pad - g->kh) / g->stride + 1 && g->Wo == (g->W + 2 * g->pad - g->kw) / g->stride + 1,
+  CAT_REQUIRE(g->Ho == (g->H + 2 * g->pad - g->kh) / g->stride + 1 && g->Wo == (g->W + 2 * padw - g->kw) / g->stride + 1,
               "conv: output size (%d,%d) inconsistent with geometry", g->Ho, g->Wo);
-  CAT_REQUIRE(g->pad_mode == CAT_PAD_ZERO || (g->pad < g->H && g->pad < g->W), "conv: reflect pad must be < input size");
+  CAT_REQUIRE(g->pad_mode == CAT_PAD_ZERO || (g->pad < g->H && padw < g->W), "conv: reflect pad must be < input size");
   a.N = g->N; a.H = g->H; a.W = g->W; a.Cin = g->Cin; a.xcs = g->xcs;
   a.Ho = g->Ho; a.Wo = g->Wo; a.Cout = g->Cout; a.ycs = g->ycs;
-  a.kh = g->kh; a.kw = g->kw; a.stride = g->stride; a.pad = g->pad; a.reflect = g->pad_mode == CAT_PAD_REFLECT;
+  a.kh = g->kh; a.kw = g->kw; a.stride = g->stride; a.pad = g->pad; a.padw = padw; a.reflect = g->pad_mode == CAT_PAD_REFLECT;
   a.act = g->act; a.slope = g->slope;
   a.wcs = g->wcs > 0 ? g->wcs : g->Cin;
   CAT_REQUIRE(a.wcs >= g->Cin, "conv: wcs < Cin");
@@ -1730,8 +1732,8 @@ static bool fwd_bk32_ok(const IgemmArgs& a) {
   return !no_bk32 && a.wvec && (a.c4 & 15) == 0 && !dbg_on;
 }
 
-static int fwd_setup(IgemmArgs& a, const cat_conv_t* g) {
-  if (int e = fill_common(a, g)) return e;
+static int fwd_setup(IgemmArgs& a, const cat_conv_t* g, int pad_w = -1) {
+  if (int e = fill_common(a, g, pad_w)) return e;
   a.cval = (g->Cin + 3) & ~3;
   a.c4 = walk_extent(a.cval);
   a.K = g->kh * g->kw * a.c4;
@@ -1750,7 +1752,8 @@ size_t cat_conv2d_fwd_ws_bytes(const cat_conv_t* g) {
   return sp.ksplit > 1 ? (size_t)sp.ksplit * a.M * g->ycs * sizeof(float) : 0;
 }
 
-static int conv_fwd_impl(const cat_conv_t* g, const float* x, const float* w, const float* bias, float* y, void* ws, cat_stream_t stream);
+static int conv_fwd_impl(const cat_conv_t* g, const float* x, const float* w, const float* bias, float* y, void* ws, cat_stream_t stream,
+                         int pad_w = -1);
 
 int cat_conv2d_fwd(const cat_conv_t* g, const float* x, const float* w, const float* bias, float* y, cat_stream_t stream) {
   return conv_fwd_impl(g, x, w, bias, y, nullptr, stream);
@@ -1760,14 +1763,24 @@ int cat_conv2d_fwd_ws(const cat_conv_t* g, const float* x, const float* w, const
   return conv_fwd_impl(g, x, w, bias, y, ws, stream);
 }
 
-static int conv_fwd_impl(const cat_conv_t* g, const float* x, const float* w, const float* bias, float* y, void* ws, cat_stream_t stream) {
+// Forward convolution with DIFFERENT implicit zero padding along H (g->pad) and W (pad_w): the 1 x 7 / 7 x 1 / 1 x 3 / 3 x 1 factorised
+// filters of the FID InceptionV3 (metric/inception.py:177-268 over torchvision's InceptionC / D / E).  Same kernels as cat_conv2d_fwd: the
+// im2col gather takes the column offset from pad_w.  Forward only (the metric network is never differentiated).
+int cat_conv2d_fwd_rect(const cat_conv_t* g, int pad_w, const float* x, const float* w, const float* bias, float* y, cat_stream_t stream) {
+  CAT_REQUIRE(pad_w >= 0 && g->pad_mode == CAT_PAD_ZERO, "conv fwd rect: zero padding only");
+  return conv_fwd_impl(g, x, w, bias, y, nullptr, stream, pad_w);
+}
+
+static int conv_fwd_impl(const cat_conv_t* g, const float* x, const float* w, const float* bias, float* y, void* ws, cat_stream_t stream,
+                         int pad_w) {
   IgemmArgs a{};
-  if (int e = fwd_setup(a, g)) return e;
+  if (int e = fwd_setup(a, g, pad_w)) return e;
+  const bool rect = pad_w >= 0 && pad_w != g->pad;
   a.a = x; a.b = w; a.bias = bias; a.out = y;
   a.cw = g->ycw > g->Cout ? g->ycw : g->Cout;
   CAT_REQUIRE(a.cw <= g->ycs, "conv fwd: ycw > ycs");
   hipStream_t s = (hipStream_t)stream;
-  if (cat::smallco_applicable(g)) {
+  if (!rect && cat::smallco_applicable(g)) {
     cat::ProfScope prof("conv_fwd_smallco", 2.0 * (double)g->N * g->Ho * g->Wo * g->Cout * g->kh * g->kw * g->Cin, 0.0, stream);
     const int ks = ws ? cat::smallco_fwd_ksplit(g) : 1;
     if (int e = cat::smallco_fwd(g, x, w, bias, y, (float*)ws, ks, s)) return e;

@@ -1,11 +1,15 @@
-"""Student inference half of `evaluate_model` (reference distillers/inception_distiller.py:204-281,
+"""`evaluate_model` on the GPU (reference distillers/inception_distiller.py:204-281,
 distillers/spade_distiller.py:96-180).
 
 The generator passes run on the HIP kernels (`model.test()` with the student in eval mode: BatchNorm students take the frozen-block
-fusion of cat_amd/frozen.py); images of the first 10 samples (or all) are written like the reference does.  The metric networks
-(InceptionV3 for FID, DRN for mIoU) need pretrained weights and datasets and stay with the reference: the integrator attaches
+fusion of cat_amd/frozen.py); images of the first 10 samples (or all) are written like the reference does.
 
-    model.fid_fn  = lambda fakes: get_fid(fakes, inception_model, npz, device=model.device, batch_size=opt.eval_batch_size)
+FID (round 5): the InceptionV3 pool3 feature extractor runs on the HIP kernels too (cat_amd.metric.InceptionV3, cat_amd.metric.get_fid --
+reference metric/inception.py, metric/fid_score.py:152-216, metric/__init__.py:11-21).  `attach_fid(model, checkpoint, real_stat_path)`
+builds it exactly as the reference's __init__ does (base_inception_distiller.py:218-234: `InceptionV3([block_idx])`, `np.load(real_stat_path)`)
+from the torchvision-keyed FID checkpoint the reference downloads; a model that carries `inception_model` + `npz` needs no `fid_fn`.
+The mIoU network (DRN + cityscapes data) stays with the reference: the integrator attaches
+
     model.miou_fn = lambda fakes, names: get_mIoU(fakes, names, drn_model, model.device, table_path=..., data_dir=..., ...)
 
 (`fakes` is the reference's list of NCHW CPU tensors, one per eval batch) and gets the reference's bookkeeping back: `is_best`,
@@ -74,13 +78,33 @@ def _track(model, value, best_attr, hist_attr, better):
     return sum(hist) / len(hist)
 
 
+def attach_fid(model, state_dict, real_stat_path=None, npz=None, dims=2048):
+    """What the reference's distiller __init__ does for FID (base_inception_distiller.py:218-234), with the feature extractor on the HIP kernels:
+    `state_dict` = the torchvision-keyed FID checkpoint (pt_inception-2015-12-05-6726825d.pth, or a path to it); `real_stat_path` = the
+    dataset's precomputed {'mu', 'sigma'} file."""
+    from ..metric import InceptionV3
+    if isinstance(state_dict, (str, bytes, os.PathLike)):
+        state_dict = torch.load(state_dict, map_location='cpu')
+    net = InceptionV3([InceptionV3.BLOCK_INDEX_BY_DIM[dims]])
+    net.load_fid_state_dict(state_dict)
+    model.inception_model = net.to(model.device).eval()
+    model.npz = npz if npz is not None else np.load(real_stat_path)
+    return net
+
+
 def evaluate(model, step, student, feed, images, want_fid, want_miou, save_all=False):
     """feed(batch): set_input / set_single_input; images(j): {'input'|'real'|'Tfake'|'Sfake': HWC uint8} of sample j of the batch."""
     if getattr(model, 'eval_dataloader', None) is None:
         raise RuntimeError('evaluate_model: attach model.eval_dataloader (the reference builds it from --dataroot in __init__; '
                            'cat_amd does not own datasets)')
     if want_fid and getattr(model, 'fid_fn', None) is None:
-        raise RuntimeError('evaluate_model: attach model.fid_fn = lambda fakes: get_fid(...) (cat_amd/distillers/evaluation.py)')
+        if getattr(model, 'inception_model', None) is not None and getattr(model, 'npz', None) is not None:
+            from .. import metric      # the reference's own call: get_fid(fakes, self.inception_model, self.npz, ...) (inception_distiller.py:246-249)
+            model.fid_fn = lambda fakes: metric.get_fid(fakes, model.inception_model, model.npz, device=model.device,
+                                                        batch_size=getattr(model.opt, 'eval_batch_size', 1), use_tqdm=False)
+        else:
+            raise RuntimeError('evaluate_model: call evaluation.attach_fid(model, fid_checkpoint, real_stat_path) or attach model.fid_fn '
+                               '(cat_amd/distillers/evaluation.py)')
     if want_miou and getattr(model, 'miou_fn', None) is None:
         raise RuntimeError('evaluate_model: attach model.miou_fn = lambda fakes, names: get_mIoU(...) (cat_amd/distillers/evaluation.py)')
     model.is_best = False

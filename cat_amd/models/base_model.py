@@ -143,5 +143,6 @@ class BaseModel(ABC):
         reducer.broadcast_parameters([getattr(self, 'net' + n) for n in self.model_names])
 
     def evaluate_model(self, step):
-        raise NotImplementedError('FID / mIoU evaluation needs the reference\'s pretrained InceptionV3 / DRN weights and datasets; it '
-                                  'is outside the accelerated hot path (SURVEY §2 rows 18-19)')
+        raise NotImplementedError('teacher-training models: evaluate with the distillers\' path -- cat_amd.distillers.evaluation.evaluate + '
+                                  'attach_fid (InceptionV3 pool3 features on the HIP kernels, cat_amd.metric); mIoU needs the reference\'s DRN '
+                                  'weights and the cityscapes data (SURVEY §2 rows 18-19)')

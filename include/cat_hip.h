@@ -239,6 +239,23 @@ int cat_avgpool3x3s2_bwd(const float* dy, float* dx, int N, int H, int W, int C,
 int cat_maxpool2x2_fwd(const float* x, float* y, int N, int H, int W, int C, int cs, cat_stream_t stream);
 int cat_maxpool2x2_bwd(const float* x, const float* dy, float* dx, int N, int H, int W, int C, int cs,
                        cat_stream_t stream);
+/* ---- evaluation path: the FID feature extractor InceptionV3, metric/inception.py:16-150, 177-300 over torchvision
+ * 0.8.2's Inception3; called from metric/fid_score.py:152-216 (get_activations_from_ims).  Inference only. ---- */
+/* nn.Conv2d with different zero padding along H (g->pad) and W (pad_w): the 1x7 / 7x1 / 1x3 / 3x1 factorised filters of InceptionC / D / E
+ * (BasicConv2d, eval-mode BatchNorm folded into w / bias by the host, ReLU = g->act).  y may point at a channel slice of a wider NHWC
+ * tensor (g->ycs = its pixel stride, g->ycw = g->Cout): torch.cat(outputs, 1) of an Inception block is never materialised separately. */
+int cat_conv2d_fwd_rect(const cat_conv_t* g, int pad_w, const float* x, const float* w, const float* bias, float* y,
+                        cat_stream_t stream);
+/* nn.MaxPool2d(k, stride, pad) (mode 0: padding = -inf) and F.avg_pool2d(k, stride, pad, count_include_pad=False) (mode 1) on C4
+ * channels (multiple of 4); x / y may be channel slices (xcs / ycs pixel strides). */
+int cat_pool2d_fwd(const float* x, int xcs, int N, int H, int W, int C4, int k, int stride, int pad, int mode, float* y, int ycs,
+                   int Ho, int Wo, cat_stream_t stream);
+/* nn.AdaptiveAvgPool2d((1, 1)): y[n][c] = mean over the HW pixels; y row stride ycs. */
+int cat_global_avgpool_fwd(const float* x, int xcs, int N, int HW, int C4, float* y, int ycs, cat_stream_t stream);
+/* y = a * F.interpolate(x, (Ho, Wo), mode='bilinear', align_corners=False) + b (metric/inception.py:129-136: resize to 299 x 299 and the
+ * 2 * x - 1 input normalisation in one pass); padding channels [C, round_up(C, 4)) are written as 0. */
+int cat_resize_bilinear_fwd(const float* x, int xcs, int N, int H, int W, int C, float* y, int ycs, int Ho, int Wo, float a, float b,
+                            cat_stream_t stream);
 /* SPADEModel.preprocess_input + get_edges (models/spade_model.py:142-179): label -> one-hot over nc channels,
  * instance ids -> 4-neighbour edge map in channel nc (inst may be NULL = --no_instance).  y: [N][H][W][cs]. */
 int cat_onehot_edges(const int* label, const int* inst, float* y, int N, int H, int W, int nc, int cs,

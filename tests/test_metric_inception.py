@@ -1,0 +1,200 @@
+"""FID feature extraction: oracle/ref_inception_cpu.py and cat_amd.metric against the REFERENCE's own run.
+
+tests/golden/inception_fid.npz was written by tools/make_golden_inception.py from the reference's metric/inception.py (InceptionV3 wrapper + its
+FIDInception* forwards) and metric/fid_score.py (get_activations_from_ims, calculate_frechet_distance) on seeded weights / images; torchvision's
+constructors -- absent offline -- came from tools/tv_inception_stub.py (the published architecture), which is what this pin cannot see.
+CPU: the oracle reproduces the fixture; host logic (checkpoint key mapping, state_dict surface, Frechet distance).  GPU: the HIP InceptionV3
+reproduces the fixture's pool3 features and block outputs at 1e-3, and `evaluate_model` computes FID without an attached `fid_fn`."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+import helpers as H
+from oracle import ref_inception_cpu as RI
+
+TOL = 1e-3
+
+
+def _fixture():
+    g = H.load('inception_fid.npz')
+    shapes = H.sd_from_shapes(g['shapes'])
+    return g, RI.seeded_state_dict(shapes, int(g['seed_w']))
+
+
+def _sub(t, cmax=6, step=3):
+    return t[:, :cmax, ::step, ::step].detach().cpu().numpy()
+
+
+def test_oracle_reproduces_the_reference_features():
+    g, sd = _fixture()
+    ims = g['ims'].astype(np.float64)
+    acts = RI.get_activations_from_ims(ims, sd, batch_size=2)
+    assert acts.shape == (3, 2048)
+    assert H.rel_err(acts, g['pool3']) < 1e-5
+    x = torch.from_numpy(ims.transpose(0, 3, 1, 2) / 255).float()
+    with torch.no_grad():
+        blocks = RI.inception_v3_blocks(sd, x)
+    assert [tuple(b.shape[1:]) for b in blocks] == [(64, 73, 73), (192, 35, 35), (768, 17, 17), (2048, 1, 1)]
+    assert H.rel_err(_sub(blocks[0]), g['block0']) < 1e-5 and H.rel_err(_sub(blocks[1]), g['block1']) < 1e-5
+    assert H.rel_err(_sub(blocks[2], 6, 2), g['block2']) < 1e-5
+    for b, chk in zip(blocks, g['block_checks']):
+        got = np.array([float(b.double().sum()), float(b.double().abs().sum()), float((b.double() ** 2).sum())])
+        np.testing.assert_allclose(got, chk, rtol=1e-4, atol=1e-4 * chk[1])
+
+
+def test_wrapper_state_dict_and_checkpoint_mapping():
+    """The product module has the reference wrapper's state_dict keys (blocks.i.j...) and loads the torchvision-keyed FID checkpoint."""
+    from cat_amd.metric import InceptionV3
+    g, sd = _fixture()
+    net = InceptionV3([3])
+    keys = list(net.state_dict().keys())
+    ref_keys = json.loads(str(g['wrapper_keys']))
+    assert len(keys) == int(g['n_wrapper_keys']) and keys[:12] == ref_keys[:12] and keys[-6:] == ref_keys[-6:]
+    missing = net.load_fid_state_dict(sd)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    assert torch.equal(net.blocks[2][4].branch7x7_2.conv.weight, sd['Mixed_6b.branch7x7_2.conv.weight'])
+    assert torch.equal(net.blocks[3][2].branch_pool.bn.running_var, sd['Mixed_7c.branch_pool.bn.running_var'])
+    assert net.blocks[2][4].branch7x7_2.conv.kernel_size == (1, 7) and net.blocks[2][4].branch7x7_2.conv.padding == (0, 3)
+    assert net.blocks[0][0].bn.eps == 0.001 and not any(p.requires_grad for p in net.parameters())
+    with pytest.raises(KeyError):
+        net.load_fid_state_dict({'Mixed_9z.conv.weight': torch.zeros(1)})
+    small = InceptionV3([1])          # fewer blocks: the deeper entries of the checkpoint are skipped
+    small.load_fid_state_dict(sd)
+    assert len(small.blocks) == 2
+
+
+def test_frechet_distance_matches_the_reference():
+    from cat_amd.metric import calculate_frechet_distance
+    g = H.load('inception_fid.npz')
+    f1, f2 = g['fd_f1'], g['fd_f2']
+    fd = calculate_frechet_distance(f1.mean(0), np.cov(f1, rowvar=False), f2.mean(0), np.cov(f2, rowvar=False))
+    assert abs(fd - float(g['fd'])) <= 1e-9 * abs(float(g['fd']))
+    assert abs(calculate_frechet_distance(f1.mean(0), np.cov(f1, rowvar=False), f1.mean(0), np.cov(f1, rowvar=False))) < 1e-6
+
+
+def test_tensor2im_batch_matches_the_single_image_form():
+    from cat_amd.distillers import evaluation as E
+    from cat_amd.metric import tensor2im_batch
+    t = torch.tanh(torch.randn(3, 3, 8, 10, generator=torch.Generator().manual_seed(3)) * 2)
+    b = tensor2im_batch(t)
+    assert b.shape == (3, 8, 10, 3) and b.dtype == np.uint8
+    for i in range(3):
+        assert np.array_equal(b[i], E.tensor2im(t[i]))
+
+
+# ---------------------------------------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+def test_hip_inception_matches_the_reference_features():
+    from cat_amd.metric import InceptionV3, get_activations_from_ims
+    g, sd = _fixture()
+    dev = torch.device('cuda', 0)
+    net = InceptionV3([3])
+    net.load_fid_state_dict(sd)
+    net = net.to(dev).eval()
+    ims = g['ims'].astype(np.float64)
+    acts = get_activations_from_ims(ims.copy(), net, batch_size=2, dims=2048, device=dev, use_tqdm=False)
+    assert acts.shape == (3, 2048) and acts.dtype == np.float64
+    err = H.rel_err(acts, g['pool3'])
+    print('\n[HIP InceptionV3 pool3 vs the reference] rel err %.2e' % err)
+    assert err < TOL
+    # every block output, and the intermediate layers they pin (resize + normalisation, rectangular filters, the three pools, slice writes)
+    full = InceptionV3([0, 1, 2, 3])
+    full.load_fid_state_dict(sd)
+    full = full.to(dev).eval()
+    x = torch.from_numpy(ims.transpose(0, 3, 1, 2) / 255).float().to(dev)
+    with torch.no_grad():
+        blocks = full(x)
+    assert [tuple(b.shape[1:]) for b in blocks] == [(64, 73, 73), (192, 35, 35), (768, 17, 17), (2048, 1, 1)]
+    assert H.rel_err(_sub(blocks[0]), g['block0']) < TOL and H.rel_err(_sub(blocks[1]), g['block1']) < TOL
+    assert H.rel_err(_sub(blocks[2], 6, 2), g['block2']) < TOL
+    for b, chk in zip(blocks, g['block_checks']):
+        bb = b.double()
+        got = np.array([float(bb.sum()), float(bb.abs().sum()), float((bb ** 2).sum())])
+        np.testing.assert_allclose(got, chk, rtol=TOL, atol=TOL * chk[1])
+    # against the oracle on another input size / batch (no resize: the network is fully convolutional, metric/inception.py:40-44)
+    from oracle import detfill
+    x2 = (detfill.images((2, 3, 139, 171), 77) + 1) / 2
+    plain = InceptionV3([2], resize_input=False)
+    plain.load_fid_state_dict(sd)
+    plain = plain.to(dev).eval()
+    with torch.no_grad():
+        y2 = plain(x2.to(dev))[0]
+        ref = RI.inception_v3_blocks(sd, x2, resize_input=False)[2]
+    assert H.rel_err(y2.cpu().numpy(), ref.numpy()) < TOL
+
+
+@pytest.mark.gpu
+def test_hip_pools_and_resize_match_torch():
+    """csrc/eval_ops.hip against torch on the host: max / average (padding excluded) pooling incl. channel-slice outputs, global average,
+    bilinear resize (align_corners=False) with the fused a * x + b."""
+    import ctypes as C
+    import torch.nn.functional as F
+    from cat_amd import _lib as L, ops
+    from cat_amd.metric import inception as M
+    from oracle import detfill
+    dev = torch.device('cuda', 0)
+    x = detfill.normal((2, 12, 13, 17), 5)
+    xd = ops.to_nhwc(x.to(dev))
+    for k, s, p, mode, ref in ((3, 2, 0, M.POOL_MAX, F.max_pool2d(x, 3, 2)), (3, 1, 1, M.POOL_MAX, F.max_pool2d(x, 3, 1, 1)),
+                               (3, 1, 1, M.POOL_AVG_EXCL, F.avg_pool2d(x, 3, 1, 1, count_include_pad=False)),
+                               (2, 2, 0, M.POOL_AVG_EXCL, F.avg_pool2d(x, 2, 2))):
+        y = M.pool2d(xd, k, s, p, mode)
+        assert H.rel_err(y.cpu().numpy(), ref.numpy()) < 1e-6, (k, s, p, mode)
+    wide = ops.empty_act(2, 20, 6, 8, dev)
+    torch.as_strided(wide, (2, 20, 6, 8), wide.stride()).fill_(7.0)
+    M.pool2d(xd, 3, 2, 0, M.POOL_MAX, wide, 8)
+    got = wide.cpu()
+    assert torch.equal(got[:, 8:20], F.max_pool2d(x, 3, 2)) and float((got[:, :8] - 7.0).abs().max()) == 0.0
+    g = M.GlobalAvgPool()(xd)
+    assert H.rel_err(g.cpu().numpy(), x.mean((2, 3), keepdim=True).numpy()) < 1e-6
+    img = (detfill.images((2, 3, 40, 56), 6) + 1) / 2
+    xi = ops.to_nhwc(img.to(dev))
+    for size in ((299, 299), (20, 31), (40, 56)):
+        y = ops.empty_act(2, 3, size[0], size[1], dev)
+        L.call('cat_resize_bilinear_fwd', ops._p(xi), ops.act_cs(xi), 2, 40, 56, 3, ops._p(y), ops.act_cs(y), size[0], size[1], 2.0, -1.0, ops._stream())
+        ref = 2 * F.interpolate(img, size=size, mode='bilinear', align_corners=False) - 1
+        assert float((y.cpu() - ref).abs().max()) < 2e-6, size
+        full = torch.as_strided(y, (2, 4, size[0], size[1]), y.stride())
+        assert float(full[:, 3].abs().max()) == 0.0          # the padding channel stays 0
+
+
+@pytest.mark.gpu
+def test_evaluate_model_computes_fid_on_the_gpu(tmp_path):
+    """evaluate_model with `inception_model` + `npz` attached the way the reference's __init__ does (base_inception_distiller.py:218-234) and
+    NO integrator callable: FID of the student's fakes = the oracle's features of the same fakes through the same Frechet formula."""
+    from cat_amd.distillers import evaluation as E
+    from cat_amd.metric import calculate_frechet_distance, tensor2im_batch
+    from oracle import detfill
+    g, sd = _fixture()
+    gs = H.load('step_in.npz')
+    meta = json.loads(str(gs['meta']))
+    opt = H.make_opt(norm='instance', track=False, ndf=meta['ndf'], dataset_mode=meta['dataset_mode'], gan_mode=meta['gan_mode'],
+                     lambda_recon=meta['lambda_recon'], lambda_distill=meta['lambda_distill'], student_ngf=16)
+    opt.log_dir, opt.eval_batch_size = str(tmp_path), 2
+    model = H.build_distiller(opt, gs['student_shapes'])
+    rng = np.random.default_rng(11)
+    feats = rng.standard_normal((64, 2048))
+    npz = {'mu': feats.mean(0), 'sigma': np.cov(feats, rowvar=False)}
+    E.attach_fid(model, sd, npz=npz)
+    assert getattr(model, 'fid_fn', None) is None
+    batches = [{'A': detfill.images((2, 3, 64, 64), 500 + i), 'B': detfill.images((2, 3, 64, 64), 600 + i),
+                'A_paths': ['a%d_%d.png' % (i, j) for j in range(2)], 'B_paths': ['b%d_%d.png' % (i, j) for j in range(2)]} for i in range(2)]
+    model.eval_dataloader = batches
+    model.best_fid, model.fids, model.is_best = 1e9, [], False
+    ret = model.evaluate_model(0)
+    assert model.fid_fn is not None and model.is_best and ret['metric/fid'] == ret['metric/fid-best']
+    # the same number from the oracle's features of the fakes the student produced
+    fakes = []
+    model.netG_student.eval()
+    for b in batches:
+        model.set_input(b) if opt.dataset_mode == 'aligned' else model.set_single_input(b)
+        model.test()
+        fakes.append(model.Sfake_B.detach().cpu().contiguous())
+    model.netG_student.train()
+    ims = tensor2im_batch(torch.cat(fakes, 0)).astype(float)
+    acts = RI.get_activations_from_ims(ims, sd, batch_size=2)
+    want = calculate_frechet_distance(npz['mu'], npz['sigma'], acts.mean(0), np.cov(acts, rowvar=False))
+    print('\n[evaluate_model FID on the GPU] %.4f, oracle features %.4f' % (ret['metric/fid'], want))
+    assert abs(ret['metric/fid'] - want) <= 2e-3 * abs(want)
