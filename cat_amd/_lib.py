@@ -62,12 +62,6 @@ class NSlice(C.Structure):
     _fields_ = [('c0', c_i), ('c', c_i), ('running_mean', c_p), ('running_var', c_p), ('num_batches', c_p)]
 
 
-class TFin(C.Structure):
-    """cat_tfin_t: in-kernel finalize descriptor (csrc/tnorm_fused.h)"""
-    _fields_ = [('gamma', c_p), ('beta', c_p), ('scale', c_p), ('shift', c_p), ('mean', c_p), ('rstd', c_p), ('sync', c_p), ('sub', c_p),
-                ('mstride', c_i), ('G', c_i), ('nslices', c_i), ('eps', c_f), ('momentum', c_f), ('slices', NSlice * TNORM_MAXSLICE)]
-
-
 class Stage1Geom(C.Structure):
     _fields_ = [(n, c_i) for n in ('N', 'H', 'W', 'xcs', 'cin', 'reflect', 'ycs', 'scs')] + [('col0', c_i * 3), ('width', c_i * 3), ('nvalid', c_i * 3)]
 
@@ -118,11 +112,6 @@ SIGNATURES = {
     'cat_tstage1_supported': (c_i, [c_i, c_i, c_i]),
     'cat_tstage1_fwd': (c_i, [C.POINTER(Stage1Geom), c_p, c_p, c_p, c_p, c_p, c_p]),
     'cat_tstage1_dgrad_supported': (c_i, [c_i, c_i, c_i]),
-    'cat_tfin_sync_words': (C.c_size_t, [c_i, c_i, c_i, c_i]),
-    'cat_tfin_sub_floats': (C.c_size_t, [c_i, c_i, c_i, c_i, c_i]),
-    'cat_tconv_fwd_fin': (c_i, [_TG, c_p, c_p, c_p, C.POINTER(TFin), c_p]),
-    'cat_tstage1_fwd_fin': (c_i, [C.POINTER(Stage1Geom), c_p, c_p, c_p, c_p, c_p, C.POINTER(TFin), c_p]),
-    'cat_dwm_fwd_fin': (c_i, [C.POINTER(DwmGeom), c_p, c_p, c_p, c_p, c_p, c_p, c_p, C.POINTER(TFin), c_p]),
     'cat_tstage1_dgrad': (c_i, [C.POINTER(Stage1Geom), c_p, c_p, c_p, c_p, c_p]),
     'cat_tnorm_finalize': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_i, c_p]),
     'cat_tnorm_finalize2': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_i, c_p]),

@@ -11,7 +11,6 @@
 //     normalised tensor is never written;  cat_affine_res_fwd is the stand-alone apply (y = act(x * scale + shift) [+ residual]) for the
 //     block output and for re-materialising a hidden activation in the backward pass.
 #include "common.h"
-#include "tnorm_fused.h"
 
 namespace {
 using cat::cdiv;
@@ -244,7 +243,6 @@ struct DwmArgs {
   float slope;
   int tiles_x, tiles;
   int ks[CAT_DWM_MAXQ];   // kernel size of each channel quad
-  cat_fin::Dev fin;       // in-kernel finalize of the depthwise stage's norms (fin.scale == nullptr: none)
 };
 
 // MAXQ = compile-time bound of p.nq (16: the training blocks; 24: frozen SPADE units with 3 x 21 -> 72 hidden channels)
@@ -349,21 +347,10 @@ __global__ __launch_bounds__(256) void dwm_fwd_kernel(DwmArgs p) {
       if (q < p.nq) {
         const f4 tot = *reinterpret_cast<const f4*>(red + (2 * half) * cs + q * 4) + *reinterpret_cast<const f4*>(red + (2 * half + 1) * cs + q * 4);
         if (pass == 0) mean[k] = tot / (float)cnt;
-        if ((tid & 127) == 0) {
-          if (p.fin.scale) {      // read by another workgroup of this launch: write-through (tnorm_fused.h)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) cat_fin::st_wt(dst + pass * p.scs + q * 4 + e, tot[e]);
-          } else {
-            *reinterpret_cast<f4*>(dst + pass * p.scs + q * 4) = tot;
-          }
-        }
+        if ((tid & 127) == 0) *reinterpret_cast<f4*>(dst + pass * p.scs + q * 4) = tot;
       }
     }
     __syncthreads();
-  }
-  if (p.fin.scale) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // threads 0 and 128 stored the rows: both waves drain, then one lane arrives
-    cat_fin::arrive_and_finalize(p.fin, p.stats, p.scs, tt, reinterpret_cast<int*>(smem), true);
   }
 }
 
@@ -441,22 +428,8 @@ int cat_reflect_pad_bwd2(const float* dxp, int pcs, float* dx, int dcs, const fl
   return cat::check_launch("reflect_pad_bwd2");
 }
 
-static int dwm_fwd_impl(const cat_dwm_t* g, const float* x, const float* scale, const float* shift, const float* w25, const float* bias, float* y,
-                        float* stats, const cat_tfin_t* fin, cat_stream_t stream);
-
 int cat_dwm_fwd(const cat_dwm_t* g, const float* x, const float* scale, const float* shift, const float* w25, const float* bias, float* y,
                 float* stats, cat_stream_t stream) {
-  return dwm_fwd_impl(g, x, scale, shift, w25, bias, y, stats, nullptr, stream);
-}
-
-int cat_dwm_fwd_fin(const cat_dwm_t* g, const float* x, const float* scale, const float* shift, const float* w25, const float* bias, float* y,
-                    float* stats, const cat_tfin_t* fin, cat_stream_t stream) {
-  CAT_REQUIRE(fin && stats, "dwm fin: needs a statistics table and a finalize descriptor");
-  return dwm_fwd_impl(g, x, scale, shift, w25, bias, y, stats, fin, stream);
-}
-
-static int dwm_fwd_impl(const cat_dwm_t* g, const float* x, const float* scale, const float* shift, const float* w25, const float* bias, float* y,
-                        float* stats, const cat_tfin_t* fin, cat_stream_t stream) {
   CAT_REQUIRE(g->nq >= 1 && g->nq <= CAT_DWM_MAXQ, "dwm: %d channel quads (max %d)", g->nq, CAT_DWM_MAXQ);
   CAT_REQUIRE((g->xcs & 3) == 0 && (g->ycs & 3) == 0 && g->xcs >= 4 * g->nq && g->ycs >= 4 * g->nq, "dwm: channel layout");
   CAT_REQUIRE(!g->reflect || (g->H > 2 && g->W > 2), "dwm: reflect padding wider than the plane");
@@ -466,7 +439,6 @@ static int dwm_fwd_impl(const cat_dwm_t* g, const float* x, const float* scale, 
   a.N = g->N; a.H = g->H; a.W = g->W; a.nq = g->nq; a.reflect = g->reflect; a.act = g->act; a.slope = g->slope;
   a.tiles_x = cdiv(g->W, TW);
   a.tiles = a.tiles_x * cdiv(g->H, TH);
-  if (int e = cat_fin_make(a.fin, fin, g->scs, g->N, g->H, g->W, TH, TW)) return e;
   for (int q = 0; q < g->nq; ++q) {
     CAT_REQUIRE(g->ks[q] == 1 || g->ks[q] == 3 || g->ks[q] == 5, "dwm: kernel size %d", g->ks[q]);
     a.ks[q] = g->ks[q];

@@ -24,7 +24,6 @@
 // [lane][4]: one coalesced 1 KB global_load_dwordx4 per wave, no address arithmetic on the vector ALU, which on gfx950 shares
 // its issue slots with the fp32 MFMA).  Filters of trainable layers are re-packed once per optimizer step.
 #include "common.h"
-#include "tnorm_fused.h"
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -105,7 +104,7 @@ __device__ __forceinline__ void mma_groups(f4 (&acc)[MT][NT], const float* tile,
 
 template <int NT, int TW>
 __global__ __launch_bounds__(256) void tconv_kernel(const cat_tconv_t g, const float* __restrict__ pack, const float* __restrict__ bias,
-                                                    float* __restrict__ y, const Launch L, const cat_fin::Dev fin) {
+                                                    float* __restrict__ y, const Launch L) {
   constexpr int MT = TW / 8;
   constexpr int MAXIT = ((TH + 4) * (TW + 4) * 4 + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -332,19 +331,11 @@ __global__ __launch_bounds__(256) void tconv_kernel(const cat_tconv_t g, const f
         const int c = j * 16 + lr, co = (j0 + j) * 16 + lr;
         if (j0 + j < L.nt_total && co < g.ycw) {
           const bool cv = co < g.Nn;
-          const float v0 = cv ? s[j] : 0.f;
-          const float v1 = cv ? (red2[c] + red2[NT * 16 + c]) + (red2[2 * NT * 16 + c] + red2[3 * NT * 16 + c]) : 0.f;
-          if (fin.scale) {      // in-kernel finalize (tnorm_fused.h): the table is read by ANOTHER workgroup of this launch -> write-through
-            cat_fin::st_wt(dst + co, v0);
-            cat_fin::st_wt(dst + g.scs + co, v1);
-          } else {
-            dst[co] = v0;
-            dst[g.scs + co] = v1;
-          }
+          dst[co] = cv ? s[j] : 0.f;
+          dst[g.scs + co] = cv ? (red2[c] + red2[NT * 16 + c]) + (red2[2 * NT * 16 + c] + red2[3 * NT * 16 + c]) : 0.f;
         }
       }
     }
-    if (fin.scale) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the storing wave drains its statistics rows before it arrives
   }
 
 #pragma unroll
@@ -370,10 +361,6 @@ __global__ __launch_bounds__(256) void tconv_kernel(const cat_tconv_t g, const f
       }
     }
   }
-  if (g.stats && fin.scale) {      // last workgroup of the launch merges the table and finalises the stage's norms (nobody waits)
-    __syncthreads();               // every wave is done with the staging tiles: the first LDS word is free
-    cat_fin::arrive_and_finalize(fin, g.stats, g.scs, tt, reinterpret_cast<int*>(smem), false);
-  }
 }
 
 // ------------------------------------------------------------------------------------------------ fused first convs of a block
@@ -386,7 +373,6 @@ struct S1Args {
   int xcs, c4, N, H, W, reflect, ycs3[3], scs;
   int nt_total[3], col0[3], width[3], nvalid[3];
   int hl, tr, tc, tiles_x, tiles;
-  cat_fin::Dev fin;      // in-kernel finalize of the stage's norms (fin.scale == nullptr: none)
 };
 
 template <int NT, bool STATS>
@@ -446,19 +432,11 @@ __device__ __forceinline__ void s1_epilogue(f4 (&acc)[2][NT], const S1Args& p, i
         const int c = j * 16 + lr;
         if (c < width) {
           const bool cv = c < nv;
-          const float v0 = cv ? s[j] : 0.f;
-          const float v1 = cv ? (red2[c] + red2[NT * 16 + c]) + (red2[2 * NT * 16 + c] + red2[3 * NT * 16 + c]) : 0.f;
-          if (p.fin.scale) {
-            cat_fin::st_wt(dst + c, v0);
-            cat_fin::st_wt(dst + p.scs + c, v1);
-          } else {
-            dst[c] = v0;
-            dst[p.scs + c] = v1;
-          }
+          dst[c] = cv ? s[j] : 0.f;
+          dst[p.scs + c] = cv ? (red2[c] + red2[NT * 16 + c]) + (red2[2 * NT * 16 + c] + red2[3 * NT * 16 + c]) : 0.f;
         }
       }
     }
-    if (p.fin.scale) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();   // red is reused by the next sub-convolution
   }
 #pragma unroll
@@ -598,12 +576,6 @@ __global__ __launch_bounds__(256) void tstage1_kernel(const S1Args p) {
   if constexpr (NA > 0) s1_epilogue<NA, STATS>(accA, p, 0, n, tt, oy0, ox0, wave, lr, lq, red);
   if constexpr (NB > 0) s1_epilogue<NB, STATS>(accB, p, 1, n, tt, oy0, ox0, wave, lr, lq, red);
   if constexpr (NC > 0) s1_epilogue<NC, STATS>(accC, p, 2, n, tt, oy0, ox0, wave, lr, lq, red);
-  if constexpr (STATS) {
-    if (p.fin.scale) {
-      __syncthreads();
-      cat_fin::arrive_and_finalize(p.fin, p.stats, p.scs, tt, reinterpret_cast<int*>(smem), false);
-    }
-  }
 }
 
 // dst[(G * nt_total + j) * 256 + lane * 4 + e]: G enumerates the MFMA groups of all chunks of one segment in consumption order
@@ -667,19 +639,7 @@ int cat_tconv_pack(const float* w, int mode, int Nn, int Ck, int ks, int wcs, in
   return cat::check_launch("tconv_pack");
 }
 
-static int tconv_fwd_impl(const cat_tconv_t* g, const float* pack, const float* bias, float* y, const cat_tfin_t* fin, cat_stream_t stream);
-
 int cat_tconv_fwd(const cat_tconv_t* g, const float* pack, const float* bias, float* y, cat_stream_t stream) {
-  return tconv_fwd_impl(g, pack, bias, y, nullptr, stream);
-}
-
-// cat_tconv_fwd with statistics whose LAST workgroup also does what cat_tnorm_finalize would do as the next launch (tnorm_fused.h)
-int cat_tconv_fwd_fin(const cat_tconv_t* g, const float* pack, const float* bias, float* y, const cat_tfin_t* fin, cat_stream_t stream) {
-  CAT_REQUIRE(fin && g->stats, "tconv fin: needs a statistics table and a finalize descriptor");
-  return tconv_fwd_impl(g, pack, bias, y, fin, stream);
-}
-
-static int tconv_fwd_impl(const cat_tconv_t* g, const float* pack, const float* bias, float* y, const cat_tfin_t* fin, cat_stream_t stream) {
   CAT_REQUIRE(g->nseg >= 1 && g->nseg <= CAT_TCONV_MAXSEG, "tconv: %d segments", g->nseg);
   CAT_REQUIRE(g->N > 0 && g->H > 0 && g->W > 0 && g->Ho > 0 && g->Wo > 0 && g->Nn > 0, "tconv: empty geometry");
   CAT_REQUIRE((g->ycs & 3) == 0 && g->ycs >= g->Nn && g->ycw <= g->ycs, "tconv: bad output stride");
@@ -732,16 +692,13 @@ static int tconv_fwd_impl(const cat_tconv_t* g, const float* pack, const float* 
   const size_t lds = (size_t)2 * L.tr * L.tc * cat_pk::PITCH * sizeof(float) + 2 * cat_pk::TABN * sizeof(int) +
                      (g->stats ? (size_t)8 * nt * 16 * sizeof(float) : 0);
   CAT_REQUIRE(lds <= 96 * 1024, "tconv: %zu bytes of LDS (max 96 KB)", lds);
-  cat_fin::Dev fd;
-  if (int e = cat_fin_make(fd, fin, g->scs, g->N, g->Ho, g->Wo, cat_pk::TH, 16)) return e;
-  CAT_REQUIRE(fin == nullptr || (L.nblk == 1 && tw == 16), "tconv fin: one workgroup per tile only");
   hipStream_t s = (hipStream_t)stream;
   cat::ProfScope prof(g->nseg > 1 ? "conv_tconv_multi" : "conv_tconv", 2.0 * (double)g->N * g->Ho * g->Wo * (g->nvalid > 0 ? g->nvalid : g->Nn) * kflops, 0.0, stream);
 #define CAT_PK_LAUNCH(NT, TW)                                                                                              \
   {                                                                                                                        \
     static cat::LdsOptIn optin;                                                                                            \
     cat::lds_optin(optin, (const void*)cat_pk::tconv_kernel<NT, TW>, 96 * 1024);                                           \
-    cat_pk::tconv_kernel<NT, TW><<<(int)grid, 256, lds, s>>>(*g, pack, bias, y, L, fd);                                        \
+    cat_pk::tconv_kernel<NT, TW><<<(int)grid, 256, lds, s>>>(*g, pack, bias, y, L);                                        \
   }
 #define CAT_PK_NT(TW)                          \
   switch (nt) {                                \
@@ -761,7 +718,7 @@ static int tconv_fwd_impl(const cat_tconv_t* g, const float* pack, const float* 
 }
 
 static int tstage1_launch(const cat_tstage1_t* g, const float* x, const float* const* packs, const float* bias, float* const* ys,
-                          const int* ycs3, float* stats, const char* what, cat_stream_t stream, const cat_tfin_t* fin = nullptr) {
+                          const int* ycs3, float* stats, const char* what, cat_stream_t stream) {
   CAT_REQUIRE(g->N > 0 && g->H > 0 && g->W > 0 && g->cin > 0 && (g->xcs & 3) == 0 && g->xcs >= g->cin, "tstage1: bad input geometry");
   CAT_REQUIRE((int64_t)g->N * g->H * g->W * g->xcs < (int64_t)4294967295LL, "tstage1: source larger than 2^32 elements");
   cat_pk::S1Args a{};
@@ -779,7 +736,6 @@ static int tstage1_launch(const cat_tstage1_t* g, const float* x, const float* c
     const int ks = k == 0 ? 5 : (k == 1 ? 3 : 1);
     kflops += (double)g->nvalid[k] * ks * ks;
   }
-  if (int e = cat_fin_make(a.fin, fin, g->scs, g->N, g->H, g->W, cat_pk::TH, 16)) return e;
   a.hl = nt[0] ? 2 : (nt[1] ? 1 : 0);
   CAT_REQUIRE(!g->reflect || (2 * a.hl + 1 <= g->H && 2 * a.hl + 1 <= g->W), "tstage1: reflect padding wider than the plane");
   a.tr = cat_pk::TH + 2 * a.hl;
@@ -811,24 +767,6 @@ int cat_tstage1_fwd(const cat_tstage1_t* g, const float* x, const float* const* 
   float* const ys[3] = {y, y, y};
   const int ycs3[3] = {g->ycs, g->ycs, g->ycs};
   return tstage1_launch(g, x, packs, bias, ys, ycs3, stats, "conv_tstage1", stream);
-}
-
-int cat_tstage1_fwd_fin(const cat_tstage1_t* g, const float* x, const float* const* packs, const float* bias, float* y, float* stats,
-                        const cat_tfin_t* fin, cat_stream_t stream) {
-  CAT_REQUIRE(y && stats && fin && (g->ycs & 3) == 0 && (g->scs & 3) == 0, "tstage1 fin: output / statistics buffers");
-  float* const ys[3] = {y, y, y};
-  const int ycs3[3] = {g->ycs, g->ycs, g->ycs};
-  return tstage1_launch(g, x, packs, bias, ys, ycs3, stats, "conv_tstage1", stream, fin);
-}
-
-size_t cat_tfin_sync_words(int G, int N, int Ho, int Wo) {
-  const int per_img = cat::cdiv(Wo, 16) * cat::cdiv(Ho, cat_pk::TH), ntile = per_img * (G == 1 ? N : 1);
-  return (size_t)G * (1 + cat::cdiv(ntile, cat_fin::SUB));
-}
-
-size_t cat_tfin_sub_floats(int scs, int G, int N, int Ho, int Wo) {
-  const int per_img = cat::cdiv(Wo, 16) * cat::cdiv(Ho, cat_pk::TH), ntile = per_img * (G == 1 ? N : 1);
-  return (size_t)G * cat::cdiv(ntile, cat_fin::SUB) * 3 * scs;
 }
 
 int cat_tstage1_supported(int w5, int w3, int w1) {

@@ -377,40 +377,6 @@ def _slices(pairs):
     return arr
 
 
-_FUSED_FIN = os.environ.get('CAT_FUSED_FINALIZE', '1') != '0'      # A/B switch (round 5): the producing launch finalises its stage's norms
-
-
-def set_fused_finalize(on):
-    global _FUSED_FIN
-    old, _FUSED_FIN = _FUSED_FIN, bool(on)
-    return old
-
-
-def fin_desc(p, key, scs, n, h, w, gamma, beta, pairs, mstride=None):
-    """(TFin descriptor, ss, mr) for a stage whose producer finalises in-kernel (csrc/tnorm_fused.h): the statistics of all tiles are merged by
-    the launch's LAST workgroup -- no cat_tnorm_finalize launch between the stage and its consumer.  The arrival counters and the partials'
-    scratch are persistent per (plan, stage, shape); the kernel returns the counters to zero.  ss / mr as _finalize returns them."""
-    G = n if p.instance else 1
-    mstride = scs if mstride is None else mstride
-    bufs = p.__dict__.setdefault('_fin_bufs', {})
-    ent = bufs.get((key, n, h, w))
-    if ent is None:
-        words = int(L.query('cat_tfin_sync_words', G, n, h, w))
-        floats = int(L.query('cat_tfin_sub_floats', scs, G, n, h, w))
-        ent = bufs[(key, n, h, w)] = (torch.zeros(words, device=p.dev, dtype=torch.int32), torch.empty(max(floats, 4), device=p.dev, dtype=torch.float32))
-    ss = torch.empty((2, G, scs), device=p.dev, dtype=torch.float32)
-    mr = torch.empty((2, G, mstride), device=p.dev, dtype=torch.float32)
-    f = L.TFin()
-    f.gamma, f.beta = (gamma.data_ptr(), beta.data_ptr()) if (p.affine and gamma is not None) else (None, None)
-    f.scale, f.shift, f.mean, f.rstd = ss[0].data_ptr(), ss[1].data_ptr(), mr[0].data_ptr(), mr[1].data_ptr()
-    f.sync, f.sub = ent[0].data_ptr(), ent[1].data_ptr()
-    f.mstride, f.G, f.nslices, f.eps, f.momentum = mstride, G, len(pairs), p.eps, p.momentum
-    for i, sl in enumerate(_slices(pairs)):
-        f.slices[i].c0, f.slices[i].c = sl.c0, sl.c
-        f.slices[i].running_mean, f.slices[i].running_var, f.slices[i].num_batches = sl.running_mean, sl.running_var, sl.num_batches
-    return f, ss, mr
-
-
 def _finalize(p, part, scs, n, h, w, gamma, beta, pairs, mstride=None):
     """-> (ss, mr): ss[0] / ss[1] = scale / shift [G][scs]; mr[0] / mr[1] = mean / rstd [G][mstride] (kept for the backward pass)."""
     G = n if p.instance else 1
@@ -434,7 +400,6 @@ def forward(block, x, save=None):
     # ---- stage 1: first convs -> Z1 (pre-norm, concatenated) + tile statistics
     z1 = torch.empty((n, h, w, p.hc1), device=dev, dtype=torch.float32)
     part1 = torch.empty((tiles, 2, p.hc1), device=dev, dtype=torch.float32)
-    st1 = None
     by_k = {g['k']: g for g in p.groups}
     if len(p.groups) == 3 and L.query('cat_tstage1_supported', by_k[5]['width'], by_k[3]['width'], by_k[1]['width']):
         # one launch: the three kernel sizes share every staged input tile
@@ -445,13 +410,7 @@ def forward(block, x, save=None):
             g = by_k[k]
             gs.col0[slot], gs.width[slot], gs.nvalid[slot] = g['off'], g['width'], sum(b['m'] for b in g['branches'])
             packs[slot] = g['pack'].data_ptr()
-        if _FUSED_FIN:
-            f1, ss1, mr1 = fin_desc(p, 's1', p.hc1, n, h, w, p.gamma1, p.beta1, [(b['o1'], b['m'], b['bn1']) for b in p.branches])
-            L.call('cat_tstage1_fwd_fin', C.byref(gs), ops._p(x), packs, ops._p(p.bias1) if p.has_bias1 else None, ops._p(z1), ops._p(part1), C.byref(f1),
-                   ops._stream())
-            st1 = (ss1, mr1)
-        else:
-            L.call('cat_tstage1_fwd', C.byref(gs), ops._p(x), packs, ops._p(p.bias1) if p.has_bias1 else None, ops._p(z1), ops._p(part1), ops._stream())
+        L.call('cat_tstage1_fwd', C.byref(gs), ops._p(x), packs, ops._p(p.bias1) if p.has_bias1 else None, ops._p(z1), ops._p(part1), ops._stream())
     else:
         for g in p.groups:
             pad = (g['k'] - 1) // 2
@@ -459,8 +418,7 @@ def forward(block, x, save=None):
             tconv.run([seg], g['pack'], (p.bias1.data_ptr() + 4 * g['off']) if p.has_bias1 else None, None, g['width'], n, h, w, h, w, ycs=p.hc1,
                       ycw=g['width'], yptr=z1.data_ptr() + 4 * g['off'], stats=part1.data_ptr() + 4 * g['off'], scs=p.hc1,
                       nvalid=sum(b['m'] for b in g['branches']))
-    if st1 is None:
-        st1 = _finalize(p, part1, p.hc1, n, h, w, p.gamma1, p.beta1, [(b['o1'], b['m'], b['bn1']) for b in p.branches])
+    st1 = _finalize(p, part1, p.hc1, n, h, w, p.gamma1, p.beta1, [(b['o1'], b['m'], b['bn1']) for b in p.branches])
     # ---- depthwise stage
     zd = std = None
     if p.dws:
@@ -473,15 +431,9 @@ def forward(block, x, save=None):
             for q in range(b['od'] // 4, (b['od'] + _cs4(b['m'])) // 4):
                 gd.ks[q] = b['kd']
         o = p.dw_in0
-        dw_args = (C.byref(gd), C.c_void_p(z1.data_ptr() + 4 * o), C.c_void_p(st1[0][0].data_ptr() + 4 * o),
-                   C.c_void_p(st1[0][1].data_ptr() + 4 * o), ops._p(p.w25), ops._p(p.biasd) if p.has_biasd else None, ops._p(zd), ops._p(partd))
-        if _FUSED_FIN:
-            fd, ssd, mrd = fin_desc(p, 'dw', p.hcd, n, h, w, p.gammad, p.betad, [(b['od'], b['m'], b['bn2']) for b in p.dws])
-            L.call('cat_dwm_fwd_fin', *dw_args, C.byref(fd), ops._stream())
-            std = (ssd, mrd)
-        else:
-            L.call('cat_dwm_fwd', *dw_args, ops._stream())
-            std = _finalize(p, partd, p.hcd, n, h, w, p.gammad, p.betad, [(b['od'], b['m'], b['bn2']) for b in p.dws])
+        L.call('cat_dwm_fwd', C.byref(gd), C.c_void_p(z1.data_ptr() + 4 * o), C.c_void_p(st1[0][0].data_ptr() + 4 * o),
+               C.c_void_p(st1[0][1].data_ptr() + 4 * o), ops._p(p.w25), ops._p(p.biasd) if p.has_biasd else None, ops._p(zd), ops._p(partd), ops._stream())
+        std = _finalize(p, partd, p.hcd, n, h, w, p.gammad, p.betad, [(b['od'], b['m'], b['bn2']) for b in p.dws])
     # ---- stage 2: the branch sum, K-concatenated, normalise + activation applied while staging
     segs = []
     for b in p.branches:
@@ -496,14 +448,9 @@ def forward(block, x, save=None):
                                       sstride=sstride_of(p.hcd)))
     t = ops.empty_act(n, c, h, w, dev)
     partp = torch.empty((tiles, 2, p.cs), device=dev, dtype=torch.float32)
+    tconv.run(segs, p.pack2, p.bias2 if p.has_bias2 else None, t, c, n, h, w, h, w, stats=partp, scs=p.cs)
     pw = block.pw_bn
-    if _FUSED_FIN:
-        fp, ssp, mrp = fin_desc(p, 'pw', p.cs, n, h, w, pw.weight, pw.bias, [(0, c, pw)], mstride=c)
-        tconv.run(segs, p.pack2, p.bias2 if p.has_bias2 else None, t, c, n, h, w, h, w, stats=partp, scs=p.cs, fin=fp)
-        stp = (ssp, mrp)
-    else:
-        tconv.run(segs, p.pack2, p.bias2 if p.has_bias2 else None, t, c, n, h, w, h, w, stats=partp, scs=p.cs)
-        stp = _finalize(p, partp, p.cs, n, h, w, pw.weight, pw.bias, [(0, c, pw)], mstride=c)
+    stp = _finalize(p, partp, p.cs, n, h, w, pw.weight, pw.bias, [(0, c, pw)], mstride=c)
     # ---- out = x + pw_bn(T)
     y = ops.empty_act(n, c, h, w, dev)
     G = n if p.instance else 1

@@ -60,9 +60,8 @@ def _ptr(t):
     return t if isinstance(t, int) else t.data_ptr()
 
 
-def run(segs, packbuf, bias, y, nn, n, h, w, ho, wo, act=L.ACT_NONE, slope=0.0, ycs=None, ycw=None, yptr=None, res=None, stats=None, scs=0, nvalid=0, fin=None):
-    """Enqueue one tconv launch.  y: NHWC activation [n, nn, ho, wo] (or pass yptr / ycs / ycw for a slice of a wider buffer).
-    fin: a _lib.TFin descriptor -- the launch's last workgroup then also finalises the norms behind `stats` (csrc/tnorm_fused.h)."""
+def run(segs, packbuf, bias, y, nn, n, h, w, ho, wo, act=L.ACT_NONE, slope=0.0, ycs=None, ycw=None, yptr=None, res=None, stats=None, scs=0, nvalid=0):
+    """Enqueue one tconv launch.  y: NHWC activation [n, nn, ho, wo] (or pass yptr / ycs / ycw for a slice of a wider buffer)."""
     g = L.TConv()
     g.N, g.H, g.W, g.Ho, g.Wo = n, h, w, ho, wo
     g.Nn = nn
@@ -83,10 +82,6 @@ def run(segs, packbuf, bias, y, nn, n, h, w, ho, wo, act=L.ACT_NONE, slope=0.0, 
         t.shift = None if s.shift is None else _ptr(s.shift)
         t.sstride = s.sstride
         t.xcs, t.c4, t.cin, t.ks, t.padv, t.act, t.slope, t.reflect, t.pack_off = s.xcs, s.c4, s.cin, s.ks, s.padv, s.act, s.slope, s.reflect, s.pack_off
-    if fin is not None:
-        L.call('cat_tconv_fwd_fin', C.byref(g), ops._p(packbuf), None if bias is None else C.c_void_p(_ptr(bias)),
-               C.c_void_p(yptr if yptr is not None else y.data_ptr()), C.byref(fin), ops._stream())
-        return y
     L.call('cat_tconv_fwd', C.byref(g), ops._p(packbuf), None if bias is None else C.c_void_p(_ptr(bias)),
            C.c_void_p(yptr if yptr is not None else y.data_ptr()), ops._stream())
     return y

@@ -335,20 +335,6 @@ typedef struct {
 int cat_tnorm_finalize(const float* part, int scs, int G, int N, int Ho, int Wo, const float* gamma, const float* beta, int nslices,
                        const cat_nslice_t* slices, float eps, float momentum, float* scale, float* shift, float* mean, float* rstd,
                        int mstride, cat_stream_t stream);   /* mean / rstd rows are mstride floats apart (scs, or C for cat_norm_bwd) */
-/* In-kernel finalize (round 5, csrc/tnorm_fused.h): the producing launch's LAST workgroup merges the tile table and writes what
- * cat_tnorm_finalize would -- scale / shift / mean / rstd, running statistics of every norm module of the stage (reference: the train-mode
- * norm_layer(...) calls of inception_modules.py:43-44,150-173,178-180) -- so the dependent ~9 us finalize launch between a stage and its
- * consumer disappears (30 per student forward).  No workgroup waits for another one: arrival counters only.  `sync`: cat_tfin_sync_words()
- * zeroed 32-bit words (the kernel returns them to zero), `sub`: cat_tfin_sub_floats() floats of scratch; both per call site. */
-typedef struct {
-  const float* gamma; const float* beta;   /* [scs] concatenated affine parameters or NULL */
-  float* scale; float* shift;              /* [G][scs] */
-  float* mean; float* rstd;                /* [G][mstride] */
-  unsigned* sync; float* sub;
-  int mstride, G, nslices;                 /* G = 1 (BatchNorm: statistics over the batch) or N (InstanceNorm) */
-  float eps, momentum;
-  cat_nslice_t slices[CAT_TNORM_MAXSLICE];
-} cat_tfin_t;
 /* The same norms as SynchronizedBatchNorm2d over several ranks (models/modules/sync_batchnorm/batchnorm.py:103-140): cat_tnorm_sums folds this
  * rank's tile table (th x tw tiles, ncls entries per tile) to sums = [sum x | sum x^2] (2 * scs floats), the host all-reduces them over RCCL --
  * ONE collective per block stage instead of one per norm layer --, and cat_tnorm_finalize_sums applies the reference's multi-replica formula
@@ -495,15 +481,6 @@ int cat_qconv_fwd(const cat_qconv_t* g, const float* pack, const float* bias, fl
 int cat_tnorm_finalize2(const float* part, int scs, int G, int N, int Ho, int Wo, int th, int tw, int ncls, const float* gamma,
                         const float* beta, int nslices, const cat_nslice_t* slices, float eps, float momentum, float* scale, float* shift,
                         float* mean, float* rstd, int mstride, cat_stream_t stream);
-
-/* producers with the in-kernel finalize (cat_tfin_t above): cat_tconv_fwd / cat_tstage1_fwd / cat_dwm_fwd + their stage's cat_tnorm_finalize */
-size_t cat_tfin_sync_words(int G, int N, int Ho, int Wo);
-size_t cat_tfin_sub_floats(int scs, int G, int N, int Ho, int Wo);
-int cat_tconv_fwd_fin(const cat_tconv_t* g, const float* pack, const float* bias, float* y, const cat_tfin_t* fin, cat_stream_t stream);
-int cat_tstage1_fwd_fin(const cat_tstage1_t* g, const float* x, const float* const* packs, const float* bias, float* y, float* stats,
-                        const cat_tfin_t* fin, cat_stream_t stream);
-int cat_dwm_fwd_fin(const cat_dwm_t* g, const float* x, const float* scale, const float* shift, const float* w25, const float* bias,
-                    float* y, float* stats, const cat_tfin_t* fin, cat_stream_t stream);
 
 #ifdef __cplusplus
 }

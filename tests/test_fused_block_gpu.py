@@ -185,47 +185,3 @@ def test_fused_block_plan_follows_replaced_parameters():
     new = blk.res_ops[0][1][1].weight
     assert new.grad is not None and blk.pw_bn.bias.grad is not None
     assert rel(new.grad, g_old) < 1e-4      # (running statistics moved between the two steps: batch statistics did not)
-
-
-@pytest.mark.parametrize('norm,padding,shape', [('batch', 'reflect', (4, 77, 48, 64)), ('instance', 'reflect', (4, 77, 48, 64)),
-                                                ('batch', 'zero', (3, 77, 50, 70)), ('batch', 'reflect', (16, 77, 64, 64))])
-def test_in_kernel_finalize_equals_the_finalize_launch(norm, padding, shape):
-    """Round 5 (csrc/tnorm_fused.h): the producing launch's last workgroup merges the tile statistics and finalises the stage's norms.  Against
-    the separate cat_tnorm_finalize launch: block output, every scale / shift / mean / rstd row the backward keeps, running statistics and batch
-    counters; the arrival counters are back at zero; three runs are bit-identical (the merge order is fixed by tile index, not by arrival) --
-    incl. ragged edge tiles, a partial last sub-group, InstanceNorm's per-image groups and the headline geometry (512 tiles, 16 sub-groups)."""
-    from cat_amd import _lib, fused_block, ops
-    _lib.load()
-    dev = torch.device('cuda:0')
-    n, c, h, w = shape
-    blk = _block(norm, dev, c, (11, 12, 18), (15, 15, 12), padding)
-    ref_blk = copy.deepcopy(blk)
-    xg = ops.to_nhwc(detfill.normal((n, c, h, w), 5).to(dev))
-    outs = []
-    with torch.no_grad():
-        for mod, fused in ((blk, True), (ref_blk, False)):
-            old = fused_block.set_fused_finalize(fused)
-            try:
-                save = {}
-                y = fused_block.forward(mod, xg, save)
-                torch.cuda.synchronize()
-                outs.append((y, save))
-            finally:
-                fused_block.set_fused_finalize(old)
-    (y1, s1), (y0, s0) = outs
-    assert rel(y1, y0) < 2e-6, rel(y1, y0)
-    for key in ('st1', 'std', 'stp'):
-        for a, b in zip(s1[key], s0[key]):      # (scale | shift), (mean | rstd)
-            assert a.shape == b.shape and rel(a, b) < 2e-6, (key, rel(a, b))
-    for (k, a), (_, b) in zip(blk.state_dict().items(), ref_blk.state_dict().items()):
-        if 'running_' in k:
-            assert rel(a, b) < 1e-6, k
-        if 'num_batches_tracked' in k:
-            assert int(a) == int(b) == 1, k
-    plan = blk._cat_fused_plan
-    assert len(plan._fin_bufs) == 3 and all(int(sync.abs().sum()) == 0 for sync, _ in plan._fin_bufs.values())
-    with torch.no_grad():      # determinism: arrival order varies from run to run, the result must not
-        runs = [fused_block.forward(blk, xg).clone() for _ in range(3)]
-    torch.cuda.synchronize()
-    assert torch.equal(runs[0], runs[1]) and torch.equal(runs[1], runs[2])
-    assert all(int(sync.abs().sum()) == 0 for sync, _ in plan._fin_bufs.values())
