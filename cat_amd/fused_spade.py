@@ -377,11 +377,14 @@ def _slices(pairs):
     return arr
 
 
-def _finalize(p, part, scs, n, h, w, gamma, beta, pairs):
+def _finalize_g(p, part, scs, n, h, w, gamma, beta, pairs):
     """(scale | shift), (mean | rstd) of every norm of a stage.  With a SynchronizedBatchNorm reducer installed (N > 1 ranks) the stage's
     statistics are exchanged ONCE: this rank's tile table -> [sum x | sum x^2] of the whole concatenation -> one all-reduce -> the
     reference's multi-replica formula (batchnorm.py:103-140: clamp(var, eps), unbiased running_var); the second tensor then holds
-    (a | b) = (inv_std | -mean * inv_std) for the split-phase backward."""
+    (a | b) = (inv_std | -mean * inv_std) for the split-phase backward.
+    A GENERATOR: it yields the tensor to be sum-reduced over the ranks and continues once that has happened -- `_drive` performs the exchange
+    on the spot (one unit), `_drive_many` runs several independent units in lockstep and merges their k-th exchanges into ONE collective
+    (the gamma|beta nets of all SPADE layers of a generator: `prepass`)."""
     ss = torch.empty((2, 1, scs), device=part.device, dtype=torch.float32)
     mr = torch.empty((2, 1, scs), device=part.device, dtype=torch.float32)
     sync = ops.bn_sync()
@@ -391,16 +394,55 @@ def _finalize(p, part, scs, n, h, w, gamma, beta, pairs):
         return ss, mr
     sums = torch.empty(2 * scs, device=part.device, dtype=torch.float32)
     L.call('cat_tnorm_sums', ops._p(part), scs, n, h, w, 8, 16, 1, ops._p(sums), ops._stream())
-    sync.all_reduce_sum_(sums)
-    STATS['collectives'] += 1
+    yield sums
     count = float(n * h * w) * sync.world_size
     L.call('cat_tnorm_finalize_sums', ops._p(sums), count, scs, ops._p(gamma), ops._p(beta), len(pairs), _slices(pairs), p.eps, p.momentum, 1,
            ops._p(ss[0]), ops._p(ss[1]), ops._p(mr[0]), ops._p(mr[1]), ops._stream())
     return ss, mr
 
 
+def _drive(gen):
+    """Run ONE unit generator to completion; every statistics exchange it asks for happens immediately (one collective each)."""
+    try:
+        req = next(gen)
+        while True:
+            ops.bn_sync().all_reduce_sum_(req)
+            STATS['collectives'] += 1
+            req = gen.send(None)
+    except StopIteration as e:
+        return e.value
+
+
+def _drive_many(gens):
+    """Run several INDEPENDENT unit generators in lockstep: the k-th exchanges of all of them travel as ONE collective (their buffers are
+    summed element-wise either way: results are bit-identical to `_drive` on each)."""
+    results, reqs = [None] * len(gens), {}
+    for i, g in enumerate(gens):
+        try:
+            reqs[i] = next(g)
+        except StopIteration as e:
+            results[i] = e.value
+    while reqs:
+        order = sorted(reqs)
+        ops.bn_sync().all_reduce_sum_many_([reqs[i] for i in order])
+        STATS['collectives'] += 1
+        nxt = {}
+        for i in order:
+            try:
+                nxt[i] = gens[i].send(None)
+            except StopIteration as e:
+                results[i] = e.value
+        reqs = nxt
+    return results
+
+
 def forward(p, x, addend, save=None):
     """The unit's forward.  `addend`: NHWC activation [n, Cout, h, w] added in the epilogue (the block's shortcut) or None."""
+    return _drive(forward_g(p, x, addend, save))
+
+
+def forward_g(p, x, addend, save=None):
+    """forward as a generator over its statistics exchanges (see _finalize_g)."""
     STATS['train_fwd'] += 1
     p.prepare()
     n, c, h, w = x.shape
@@ -425,7 +467,7 @@ def forward(p, x, addend, save=None):
             tconv.run([seg], g['pack'], (p.bias1.data_ptr() + 4 * g['off']) if p.has_bias1 else None, None, g['width'], n, h, w, h, w, ycs=p.hc1,
                       ycw=g['width'], yptr=z1.data_ptr() + 4 * g['off'], stats=part1.data_ptr() + 4 * g['off'], scs=p.hc1,
                       nvalid=sum(b['m'] for b in g['branches']))
-    st1 = _finalize(p, part1, p.hc1, n, h, w, p.gamma1, p.beta1, [(b['o1'], b['m'], b['bn1']) for b in p.branches])
+    st1 = yield from _finalize_g(p, part1, p.hc1, n, h, w, p.gamma1, p.beta1, [(b['o1'], b['m'], b['bn1']) for b in p.branches])
     zd = std = None
     if p.dws:
         zd = torch.empty((n, h, w, p.hcd), device=dev, dtype=torch.float32)
@@ -439,7 +481,7 @@ def forward(p, x, addend, save=None):
         o = p.dw_in0
         L.call('cat_dwm_fwd', C.byref(gd), C.c_void_p(z1.data_ptr() + 4 * o), C.c_void_p(st1[0][0].data_ptr() + 4 * o),
                C.c_void_p(st1[0][1].data_ptr() + 4 * o), ops._p(p.w25), ops._p(p.biasd) if p.has_biasd else None, ops._p(zd), ops._p(partd), ops._stream())
-        std = _finalize(p, partd, p.hcd, n, h, w, p.gammad, p.betad, [(b['od'], b['m'], b['bn2']) for b in p.dws])
+        std = yield from _finalize_g(p, partd, p.hcd, n, h, w, p.gammad, p.betad, [(b['od'], b['m'], b['bn2']) for b in p.dws])
     segs = []
     for b in p.branches:
         if b['kind'] == 'res':
@@ -524,7 +566,7 @@ def forward_eval(p, x, addend):
     return y
 
 
-def _norm_bwd(p, n, hw, c, cs, x, dy, gamma, beta, mr, dgamma, dbeta, synced=False):
+def _norm_bwd_g(p, n, hw, c, cs, x, dy, gamma, beta, mr, dgamma, dbeta, synced=False):
     dx = torch.empty((n, hw, cs), device=x.device, dtype=torch.float32)
     if synced:
         # SynchronizedBatchNorm backward over ranks: local [sum g | sum g * xhat] of the whole stage -> ONE all-reduce -> apply; the parameter
@@ -539,8 +581,7 @@ def _norm_bwd(p, n, hw, c, cs, x, dy, gamma, beta, mr, dgamma, dbeta, synced=Fal
         L.call('cat_bn_stats_bwd', ops._p(x), ops._p(dy), ops._p(gamma), ops._p(beta), ops._p(mr[0]), ops._p(mr[1]), m, c, cs, p.act, p.slope,
                ops._p(sums), ops._p(ws), st)
         local = sums.clone()
-        sync.all_reduce_sum_(sums)
-        STATS['collectives'] += 1
+        yield sums      # sum-reduced over the ranks by the driver (_drive / _drive_many)
         L.call('cat_bn_apply_bwd', ops._p(x), ops._p(dy), ops._p(gamma), ops._p(beta), ops._p(mr[0]), ops._p(mr[1]), ops._p(sums),
                float(m * sync.world_size), ops._p(local), ops._p(dx), ops._p(dgamma), ops._p(dbeta), 0, m, c, cs, p.act, p.slope, st)
         return dx
@@ -563,7 +604,7 @@ class _UnitFn(torch.autograd.Function):
         if addend is not None:
             addend = ops.conform(addend)
         save = {}
-        y = forward(plan, x, addend, save)
+        y = _drive(forward_g(plan, x, addend, save))
         ctx.plan = plan
         ctx.synced = ops.bn_sync() is not None      # statistics over all ranks: (a | b) saved instead of (mean | rstd)
         ctx.has_dw = save['zd'] is not None
@@ -576,195 +617,272 @@ class _UnitFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        p = ctx.plan
-        STATS['bwd'] += 1
-        saved = ctx.saved_tensors
-        x, z1, ss1, mr1 = saved[:4]
-        zd, ssd, mrd = saved[4:] if ctx.has_dw else (None, None, None)
-        dt = ops.conform(dy)            # no closing norm: the gradient of the branch sum IS dy (and so is the addend's)
-        if ops.act_cs(dt) != p.cso:
-            raise RuntimeError('fused SPADE unit backward: gradient pixel stride differs from the activation')
-        p.prepare(backward=True)
-        n, c, h, w = x.shape
-        dev, hw, m_pix = x.device, h * w, n * h * w
-        st = ops._stream()
-        grads = {}
-        side = ops.SideJobs(dev)
+        return _drive(_backward_g(ctx, dy))
 
-        def put_side(param, kernel):
-            def job():
-                grads[id(param)] = ops._write_param_grad(param, lambda dst_, acc: kernel(dst_, acc, ops._stream()))
-            side.run(job)
 
-        # ---- re-materialise the hidden activations (inputs of the second convs / of the depthwise convs)
-        a1 = torch.empty((n, h, w, p.hc1), device=dev, dtype=torch.float32)
-        L.call('cat_affine_res_fwd', ops._p(z1), p.hc1, ops._p(ss1[0]), ops._p(ss1[1]), 0, None, 0, ops._p(a1), p.hc1, 1, m_pix, p.hc1, p.act, p.slope, st)
-        da1 = torch.empty((n, h, w, p.hc1), device=dev, dtype=torch.float32)
-        ad = dad = None
-        if ctx.has_dw:
-            ad = torch.empty((n, h, w, p.hcd), device=dev, dtype=torch.float32)
-            L.call('cat_affine_res_fwd', ops._p(zd), p.hcd, ops._p(ssd[0]), ops._p(ssd[1]), 0, None, 0, ops._p(ad), p.hcd, 1, m_pix, p.hcd, p.act, p.slope, st)
-            dad = torch.empty((n, h, w, p.hcd), device=dev, dtype=torch.float32)
-        # ---- second convs: weight gradients from (hidden activation slice, dT); input gradients into slices of dA1 / dAd
-        side.fork()
-        for b in p.branches:
-            res = b['kind'] == 'res'
-            k2, m, w1 = b['k2'], b['m'], b['w1']
-            pad2 = (k2 - 1) // 2
-            src, scs_, o = (a1, p.hc1, b['o1']) if res else (ad, p.hcd, b['od'])
-            dst, dcs = (da1, p.hc1) if res else (dad, p.hcd)
-            xptr = C.c_void_p(src.data_ptr() + 4 * o)
+def _backward_g(ctx, dy):
+    """A unit's backward as a generator over its statistics exchanges.  `ctx`: anything with plan / synced / has_dw / has_add / saved_tensors /
+    needs_input_grad (the autograd context of _UnitFn, or the per-unit record of _PrepassFn)."""
+    p = ctx.plan
+    STATS['bwd'] += 1
+    saved = ctx.saved_tensors
+    x, z1, ss1, mr1 = saved[:4]
+    zd, ssd, mrd = saved[4:] if ctx.has_dw else (None, None, None)
+    dt = ops.conform(dy)            # no closing norm: the gradient of the branch sum IS dy (and so is the addend's)
+    if ops.act_cs(dt) != p.cso:
+        raise RuntimeError('fused SPADE unit backward: gradient pixel stride differs from the activation')
+    p.prepare(backward=True)
+    n, c, h, w = x.shape
+    dev, hw, m_pix = x.device, h * w, n * h * w
+    st = ops._stream()
+    grads = {}
+    side = ops.SideJobs(dev)
 
-            def kw(dst_, acc, sst, xptr=xptr, m=m, scs_=scs_, k2=k2, pad2=pad2):
-                gw = ops._conv_geom(n, h, w, m, scs_, h, w, p.Cout, p.cso, k2, k2, 1, pad2, L.PAD_ZERO, wcs=ops._grad_wcs(dst_))
-                ws = ops.workspace(L.query('cat_conv2d_wgrad_ws_bytes', C.byref(gw)), dev)
-                L.call('cat_conv2d_wgrad', C.byref(gw), xptr, ops._p(dt), ops._p(dst_), acc, ops._p(ws), sst)
-            if res or not p.merge2:
-                put_side(b['conv2'].weight, kw)
-            if p.s1d is not None and (b is p.s1d[0] or b is p.s1d[1] or not res):
-                continue            # input gradient: the merged launch below
-            seg = tconv.Segment(None, k2, k2 - 1 - pad2, False, b['d2off'], c4=p.cso, cin=p.Cout, xcs=p.cso, ptr=dt.data_ptr())
-            tconv.run([seg], p.dpack2, None, None, m, n, h, w, h, w, ycs=dcs, ycw=w1, yptr=dst.data_ptr() + 4 * o)
-        if p.s1d is not None:
-            r5, r3 = p.s1d
-            gs = L.Stage1Geom()
-            gs.N, gs.H, gs.W, gs.xcs, gs.cin, gs.reflect, gs.ycs, gs.scs = n, h, w, p.cso, p.Cout, 0, 0, 0
-            packs, dxs, dxcs = (C.c_void_p * 3)(), (C.c_void_p * 3)(), (C.c_int * 3)(p.hc1, p.hc1, p.hcd)
-            for slot, (col0, width, nvalid, pk, dst) in enumerate(((r5['o1'], r5['w1'], r5['m'], p.dpack2.data_ptr() + 4 * r5['d2off'], da1),
-                                                                   (r3['o1'], r3['w1'], r3['m'], p.dpack2.data_ptr() + 4 * r3['d2off'], da1),
-                                                                   (0, p.hcd, sum(b['m'] for b in p.dws), p.dpack2_dw.data_ptr(), dad))):
-                gs.col0[slot], gs.width[slot], gs.nvalid[slot] = col0, width, nvalid
-                packs[slot], dxs[slot] = pk, dst.data_ptr()
-            L.call('cat_tstage1_dgrad', C.byref(gs), ops._p(dt), packs, dxs, dxcs, ops._stream())
-        if p.merge2:
-            def kw2(sst):
-                gw = ops._conv_geom(n, h, w, p.hcd, p.hcd, h, w, p.Cout, p.cso, 1, 1, 1, 0, L.PAD_ZERO, wcs=p.hcd)
-                ws = ops.workspace(L.query('cat_conv2d_wgrad_ws_bytes', C.byref(gw)), dev)
-                L.call('cat_conv2d_wgrad', C.byref(gw), ops._p(ad), ops._p(dt), ops._p(p.gv['w2']), 0, ops._p(ws), sst)
-            side.run(lambda: kw2(ops._stream()))
-        if p.has_bias2:
-            _channel_sum(dt, m_pix, p.Cout, p.cso, p.gv['c2'])
-        # ---- depthwise stage
-        if ctx.has_dw:
-            dzd = _norm_bwd(p, n, hw, p.hcd, p.hcd, zd, dad, p.gammad, p.betad, mrd, p.gv['gd'], p.gv['bd'], ctx.synced)
-            if p.has_biasd:
-                _channel_sum(dzd, m_pix, p.hcd, p.hcd, p.gv['cd'])
-            nb = len(p.dws)
-            gd = L.DwmGeom()
-            gd.N, gd.H, gd.W, gd.nq, gd.xcs, gd.ycs, gd.scs = n, h, w, p.hcd // 4, p.hc1, p.hcd, p.hcd
-            gd.reflect = 0
-            for b in p.dws:
-                for q in range(b['od'] // 4, (b['od'] + _cs4(b['m'])) // 4):
-                    gd.ks[q] = b['kd']
-            wts = [b['dconv'].weight for b in p.dws]
-            tg = [ops._grad_target(q) for q in wts]
-            if all(t_ is not None for t_ in tg):
-                fresh = {q._cat_grad_state['fresh'] for q in wts}
-                if len(fresh) != 1:
-                    raise RuntimeError('fused SPADE unit backward: depthwise gradient buffers out of sync')
-                acc_dw, dsts = (0 if fresh.pop() else 1), tg
-                for q in wts:
-                    q._cat_grad_state['fresh'] = False
-                    grads[id(q)] = None
-            else:
-                acc_dw, dsts = 0, [torch.empty_like(q) for q in wts]
-                for q, d_ in zip(wts, dsts):
-                    if ops._grad_target(q) is None:
-                        grads[id(q)] = d_
-            IA = C.c_int * nb
-            wsd = ops.workspace(L.query('cat_dwm_bwd_ws_bytes', C.byref(gd)), dev)
-            L.call('cat_dwm_bwd', C.byref(gd), C.c_void_p(a1.data_ptr() + 4 * p.dw_in0), ops._p(dzd), ops._p(p.w25),
-                   C.c_void_p(da1.data_ptr() + 4 * p.dw_in0), p.hc1, nb, IA(*[b['od'] for b in p.dws]), IA(*[b['m'] for b in p.dws]),
-                   IA(*[b['kd'] for b in p.dws]), (C.c_void_p * nb)(*[d_.data_ptr() for d_ in dsts]), acc_dw, ops._p(wsd), st)
-            if not all(t_ is not None for t_ in tg):
-                for q, d_ in zip(wts, dsts):
-                    tq = ops._grad_target(q)
-                    if tq is not None:
-                        (tq.copy_ if q._cat_grad_state['fresh'] else tq.add_)(d_)
-                        q._cat_grad_state['fresh'] = False
-                        grads[id(q)] = None
-        # ---- stage-1 norms (all branches at once)
-        dz1 = _norm_bwd(p, n, hw, p.hc1, p.hc1, z1, da1, p.gamma1, p.beta1, mr1, p.gv['g1'], p.gv['b1'], ctx.synced)
-        if p.has_bias1:
-            _channel_sum(dz1, m_pix, p.hc1, p.hc1, p.gv['c1'])
-        # ---- first convs: weight gradients from (x, dZ1 slice)
-        side.refork()
-        if p.merge1 is not None:
-            g1 = p.merge1
+    def put_side(param, kernel):
+        def job():
+            grads[id(param)] = ops._write_param_grad(param, lambda dst_, acc: kernel(dst_, acc, ops._stream()))
+        side.run(job)
 
-            def kw1m(sst):
-                gw = ops._conv_geom(n, h, w, c, ops.act_cs(x), h, w, g1['width'], p.hc1, 1, 1, 1, 0, L.PAD_ZERO, wcs=p.csi)
-                ws = ops.workspace(L.query('cat_conv2d_wgrad_ws_bytes', C.byref(gw)), dev)
-                L.call('cat_conv2d_wgrad', C.byref(gw), ops._p(x), C.c_void_p(dz1.data_ptr() + 4 * g1['off']), ops._p(p.gv['w1']), 0, ops._p(ws), sst)
-            side.run(lambda: kw1m(ops._stream()))
-        for b in p.branches:
-            if p.merge1 is not None and b['k'] == 1:
-                continue
-            k, m = b['k'], b['m']
-            pad1 = (k - 1) // 2
-            dyp = C.c_void_p(dz1.data_ptr() + 4 * b['o1'])
+    # ---- re-materialise the hidden activations (inputs of the second convs / of the depthwise convs)
+    a1 = torch.empty((n, h, w, p.hc1), device=dev, dtype=torch.float32)
+    L.call('cat_affine_res_fwd', ops._p(z1), p.hc1, ops._p(ss1[0]), ops._p(ss1[1]), 0, None, 0, ops._p(a1), p.hc1, 1, m_pix, p.hc1, p.act, p.slope, st)
+    da1 = torch.empty((n, h, w, p.hc1), device=dev, dtype=torch.float32)
+    ad = dad = None
+    if ctx.has_dw:
+        ad = torch.empty((n, h, w, p.hcd), device=dev, dtype=torch.float32)
+        L.call('cat_affine_res_fwd', ops._p(zd), p.hcd, ops._p(ssd[0]), ops._p(ssd[1]), 0, None, 0, ops._p(ad), p.hcd, 1, m_pix, p.hcd, p.act, p.slope, st)
+        dad = torch.empty((n, h, w, p.hcd), device=dev, dtype=torch.float32)
+    # ---- second convs: weight gradients from (hidden activation slice, dT); input gradients into slices of dA1 / dAd
+    side.fork()
+    for b in p.branches:
+        res = b['kind'] == 'res'
+        k2, m, w1 = b['k2'], b['m'], b['w1']
+        pad2 = (k2 - 1) // 2
+        src, scs_, o = (a1, p.hc1, b['o1']) if res else (ad, p.hcd, b['od'])
+        dst, dcs = (da1, p.hc1) if res else (dad, p.hcd)
+        xptr = C.c_void_p(src.data_ptr() + 4 * o)
 
-            def kw1(dst_, acc, sst, dyp=dyp, m=m, k=k, pad1=pad1):
-                gw = ops._conv_geom(n, h, w, c, ops.act_cs(x), h, w, m, p.hc1, k, k, 1, pad1, L.PAD_ZERO, wcs=ops._grad_wcs(dst_))
-                ws = ops.workspace(L.query('cat_conv2d_wgrad_ws_bytes', C.byref(gw)), dev)
-                L.call('cat_conv2d_wgrad', C.byref(gw), ops._p(x), dyp, ops._p(dst_), acc, ops._p(ws), sst)
-            put_side(b['conv1'].weight, kw1)
-        # ---- first convs: the input gradients as ONE K-concatenated launch
-        dx = None
-        if ctx.needs_input_grad[0]:
-            segs = []
-            for b in p.branches:
-                pad1 = (b['k'] - 1) // 2
-                segs.append(tconv.Segment(None, b['k'], pad1, False, b['d1off'], c4=b['w1'], cin=b['m'], xcs=p.hc1, ptr=dz1.data_ptr() + 4 * b['o1']))
-            dx = ops.empty_act(n, c, h, w, dev)
-            tconv.run(segs, p.dpack1, None, dx, c, n, h, w, h, w)
-        side.join()
-        # ---- scatter the concatenated parameter gradients
-        all_t = [q for _, _, _, q in p.targets] + [t2[5] for t2 in p.targets2d]
-        owned = [getattr(q, '_cat_grad_view', None) is not None for q in all_t]
-        if all_t and all(owned):
-            fresh = {q._cat_grad_state['fresh'] for q in all_t}
+        def kw(dst_, acc, sst, xptr=xptr, m=m, scs_=scs_, k2=k2, pad2=pad2):
+            gw = ops._conv_geom(n, h, w, m, scs_, h, w, p.Cout, p.cso, k2, k2, 1, pad2, L.PAD_ZERO, wcs=ops._grad_wcs(dst_))
+            ws = ops.workspace(L.query('cat_conv2d_wgrad_ws_bytes', C.byref(gw)), dev)
+            L.call('cat_conv2d_wgrad', C.byref(gw), xptr, ops._p(dt), ops._p(dst_), acc, ops._p(ws), sst)
+        if res or not p.merge2:
+            put_side(b['conv2'].weight, kw)
+        if p.s1d is not None and (b is p.s1d[0] or b is p.s1d[1] or not res):
+            continue            # input gradient: the merged launch below
+        seg = tconv.Segment(None, k2, k2 - 1 - pad2, False, b['d2off'], c4=p.cso, cin=p.Cout, xcs=p.cso, ptr=dt.data_ptr())
+        tconv.run([seg], p.dpack2, None, None, m, n, h, w, h, w, ycs=dcs, ycw=w1, yptr=dst.data_ptr() + 4 * o)
+    if p.s1d is not None:
+        r5, r3 = p.s1d
+        gs = L.Stage1Geom()
+        gs.N, gs.H, gs.W, gs.xcs, gs.cin, gs.reflect, gs.ycs, gs.scs = n, h, w, p.cso, p.Cout, 0, 0, 0
+        packs, dxs, dxcs = (C.c_void_p * 3)(), (C.c_void_p * 3)(), (C.c_int * 3)(p.hc1, p.hc1, p.hcd)
+        for slot, (col0, width, nvalid, pk, dst) in enumerate(((r5['o1'], r5['w1'], r5['m'], p.dpack2.data_ptr() + 4 * r5['d2off'], da1),
+                                                               (r3['o1'], r3['w1'], r3['m'], p.dpack2.data_ptr() + 4 * r3['d2off'], da1),
+                                                               (0, p.hcd, sum(b['m'] for b in p.dws), p.dpack2_dw.data_ptr(), dad))):
+            gs.col0[slot], gs.width[slot], gs.nvalid[slot] = col0, width, nvalid
+            packs[slot], dxs[slot] = pk, dst.data_ptr()
+        L.call('cat_tstage1_dgrad', C.byref(gs), ops._p(dt), packs, dxs, dxcs, ops._stream())
+    if p.merge2:
+        def kw2(sst):
+            gw = ops._conv_geom(n, h, w, p.hcd, p.hcd, h, w, p.Cout, p.cso, 1, 1, 1, 0, L.PAD_ZERO, wcs=p.hcd)
+            ws = ops.workspace(L.query('cat_conv2d_wgrad_ws_bytes', C.byref(gw)), dev)
+            L.call('cat_conv2d_wgrad', C.byref(gw), ops._p(ad), ops._p(dt), ops._p(p.gv['w2']), 0, ops._p(ws), sst)
+        side.run(lambda: kw2(ops._stream()))
+    if p.has_bias2:
+        _channel_sum(dt, m_pix, p.Cout, p.cso, p.gv['c2'])
+    # ---- depthwise stage
+    if ctx.has_dw:
+        dzd = yield from _norm_bwd_g(p, n, hw, p.hcd, p.hcd, zd, dad, p.gammad, p.betad, mrd, p.gv['gd'], p.gv['bd'], ctx.synced)
+        if p.has_biasd:
+            _channel_sum(dzd, m_pix, p.hcd, p.hcd, p.gv['cd'])
+        nb = len(p.dws)
+        gd = L.DwmGeom()
+        gd.N, gd.H, gd.W, gd.nq, gd.xcs, gd.ycs, gd.scs = n, h, w, p.hcd // 4, p.hc1, p.hcd, p.hcd
+        gd.reflect = 0
+        for b in p.dws:
+            for q in range(b['od'] // 4, (b['od'] + _cs4(b['m'])) // 4):
+                gd.ks[q] = b['kd']
+        wts = [b['dconv'].weight for b in p.dws]
+        tg = [ops._grad_target(q) for q in wts]
+        if all(t_ is not None for t_ in tg):
+            fresh = {q._cat_grad_state['fresh'] for q in wts}
             if len(fresh) != 1:
-                raise RuntimeError('fused SPADE unit backward: gradient buffers of one unit out of sync')
-            views = tuple(q._cat_grad_view.data_ptr() for q in all_t)
-            if p.scatter_jobs is None or p.scatter_jobs[3] != views:
-                jobs = [dict(kind=3, srcs=[p.gv[v].data_ptr() + 4 * o, q._cat_grad_view.data_ptr()], nsrc=2, n=cnt, threads=cnt) for v, o, cnt, q in p.targets]
-                # a one-channel conv weight is stored unpadded (wcs 1): never more columns than the destination row holds
-                for v, o, rows, cols, sstr_, q in p.targets2d:
-                    wcs_q = ops._grad_wcs(q._cat_grad_view)
-                    cq = min(cols, wcs_q)
-                    jobs.append(dict(kind=4, srcs=[p.gv[v].data_ptr() + 4 * o, q._cat_grad_view.data_ptr()], nsrc=2, n=rows * cq, cs=cq, wn=sstr_,
-                                     wcs=wcs_q, threads=rows * cq))
-                p.scatter_jobs = p._jobs_to_dev(jobs) + (views,)
-            tj, nj, nbk, _ = p.scatter_jobs
-            L.call('cat_prep_run', ops._p(tj), nj, nbk, 0 if fresh.pop() else 1, st)
-            for q in all_t:
+                raise RuntimeError('fused SPADE unit backward: depthwise gradient buffers out of sync')
+            acc_dw, dsts = (0 if fresh.pop() else 1), tg
+            for q in wts:
                 q._cat_grad_state['fresh'] = False
                 grads[id(q)] = None
         else:
-            def deliver(q, gq):
-                tgt = getattr(q, '_cat_grad_view', None)
-                if tgt is not None:
-                    stq = q._cat_grad_state
-                    (tgt.copy_ if stq['fresh'] else tgt.add_)(gq)
-                    stq['fresh'] = False
-                    gq = None
-                grads[id(q)] = gq
-            for v, o, cnt, q in p.targets:
-                flat = p.gv[v][o:o + cnt]
-                if q.dim() == 4:      # rows of the merged 1 x 1 weight gradient: back into the parameter's [O][1][1][wcs] storage
-                    gq = ops.padded_weight_like(q.shape, dev)
-                    torch.as_strided(gq, (cnt,), (1,), gq.storage_offset()).copy_(flat)
-                else:
-                    gq = flat.clone()
-                deliver(q, gq)
+            acc_dw, dsts = 0, [torch.empty_like(q) for q in wts]
+            for q, d_ in zip(wts, dsts):
+                if ops._grad_target(q) is None:
+                    grads[id(q)] = d_
+        IA = C.c_int * nb
+        wsd = ops.workspace(L.query('cat_dwm_bwd_ws_bytes', C.byref(gd)), dev)
+        L.call('cat_dwm_bwd', C.byref(gd), C.c_void_p(a1.data_ptr() + 4 * p.dw_in0), ops._p(dzd), ops._p(p.w25),
+               C.c_void_p(da1.data_ptr() + 4 * p.dw_in0), p.hc1, nb, IA(*[b['od'] for b in p.dws]), IA(*[b['m'] for b in p.dws]),
+               IA(*[b['kd'] for b in p.dws]), (C.c_void_p * nb)(*[d_.data_ptr() for d_ in dsts]), acc_dw, ops._p(wsd), st)
+        if not all(t_ is not None for t_ in tg):
+            for q, d_ in zip(wts, dsts):
+                tq = ops._grad_target(q)
+                if tq is not None:
+                    (tq.copy_ if q._cat_grad_state['fresh'] else tq.add_)(d_)
+                    q._cat_grad_state['fresh'] = False
+                    grads[id(q)] = None
+    # ---- stage-1 norms (all branches at once)
+    dz1 = yield from _norm_bwd_g(p, n, hw, p.hc1, p.hc1, z1, da1, p.gamma1, p.beta1, mr1, p.gv['g1'], p.gv['b1'], ctx.synced)
+    if p.has_bias1:
+        _channel_sum(dz1, m_pix, p.hc1, p.hc1, p.gv['c1'])
+    # ---- first convs: weight gradients from (x, dZ1 slice)
+    side.refork()
+    if p.merge1 is not None:
+        g1 = p.merge1
+
+        def kw1m(sst):
+            gw = ops._conv_geom(n, h, w, c, ops.act_cs(x), h, w, g1['width'], p.hc1, 1, 1, 1, 0, L.PAD_ZERO, wcs=p.csi)
+            ws = ops.workspace(L.query('cat_conv2d_wgrad_ws_bytes', C.byref(gw)), dev)
+            L.call('cat_conv2d_wgrad', C.byref(gw), ops._p(x), C.c_void_p(dz1.data_ptr() + 4 * g1['off']), ops._p(p.gv['w1']), 0, ops._p(ws), sst)
+        side.run(lambda: kw1m(ops._stream()))
+    for b in p.branches:
+        if p.merge1 is not None and b['k'] == 1:
+            continue
+        k, m = b['k'], b['m']
+        pad1 = (k - 1) // 2
+        dyp = C.c_void_p(dz1.data_ptr() + 4 * b['o1'])
+
+        def kw1(dst_, acc, sst, dyp=dyp, m=m, k=k, pad1=pad1):
+            gw = ops._conv_geom(n, h, w, c, ops.act_cs(x), h, w, m, p.hc1, k, k, 1, pad1, L.PAD_ZERO, wcs=ops._grad_wcs(dst_))
+            ws = ops.workspace(L.query('cat_conv2d_wgrad_ws_bytes', C.byref(gw)), dev)
+            L.call('cat_conv2d_wgrad', C.byref(gw), ops._p(x), dyp, ops._p(dst_), acc, ops._p(ws), sst)
+        put_side(b['conv1'].weight, kw1)
+    # ---- first convs: the input gradients as ONE K-concatenated launch
+    dx = None
+    if ctx.needs_input_grad[0]:
+        segs = []
+        for b in p.branches:
+            pad1 = (b['k'] - 1) // 2
+            segs.append(tconv.Segment(None, b['k'], pad1, False, b['d1off'], c4=b['w1'], cin=b['m'], xcs=p.hc1, ptr=dz1.data_ptr() + 4 * b['o1']))
+        dx = ops.empty_act(n, c, h, w, dev)
+        tconv.run(segs, p.dpack1, None, dx, c, n, h, w, h, w)
+    side.join()
+    # ---- scatter the concatenated parameter gradients
+    all_t = [q for _, _, _, q in p.targets] + [t2[5] for t2 in p.targets2d]
+    owned = [getattr(q, '_cat_grad_view', None) is not None for q in all_t]
+    if all_t and all(owned):
+        fresh = {q._cat_grad_state['fresh'] for q in all_t}
+        if len(fresh) != 1:
+            raise RuntimeError('fused SPADE unit backward: gradient buffers of one unit out of sync')
+        views = tuple(q._cat_grad_view.data_ptr() for q in all_t)
+        if p.scatter_jobs is None or p.scatter_jobs[3] != views:
+            jobs = [dict(kind=3, srcs=[p.gv[v].data_ptr() + 4 * o, q._cat_grad_view.data_ptr()], nsrc=2, n=cnt, threads=cnt) for v, o, cnt, q in p.targets]
+            # a one-channel conv weight is stored unpadded (wcs 1): never more columns than the destination row holds
             for v, o, rows, cols, sstr_, q in p.targets2d:
+                wcs_q = ops._grad_wcs(q._cat_grad_view)
+                cq = min(cols, wcs_q)
+                jobs.append(dict(kind=4, srcs=[p.gv[v].data_ptr() + 4 * o, q._cat_grad_view.data_ptr()], nsrc=2, n=rows * cq, cs=cq, wn=sstr_,
+                                 wcs=wcs_q, threads=rows * cq))
+            p.scatter_jobs = p._jobs_to_dev(jobs) + (views,)
+        tj, nj, nbk, _ = p.scatter_jobs
+        L.call('cat_prep_run', ops._p(tj), nj, nbk, 0 if fresh.pop() else 1, st)
+        for q in all_t:
+            q._cat_grad_state['fresh'] = False
+            grads[id(q)] = None
+    else:
+        def deliver(q, gq):
+            tgt = getattr(q, '_cat_grad_view', None)
+            if tgt is not None:
+                stq = q._cat_grad_state
+                (tgt.copy_ if stq['fresh'] else tgt.add_)(gq)
+                stq['fresh'] = False
+                gq = None
+            grads[id(q)] = gq
+        for v, o, cnt, q in p.targets:
+            flat = p.gv[v][o:o + cnt]
+            if q.dim() == 4:      # rows of the merged 1 x 1 weight gradient: back into the parameter's [O][1][1][wcs] storage
                 gq = ops.padded_weight_like(q.shape, dev)
-                cols = min(cols, ops.weight_wcs(gq))
-                src2 = torch.as_strided(p.gv[v], (rows, cols), (sstr_, 1), o)
-                torch.as_strided(gq, (rows, cols), (ops.weight_wcs(gq), 1), gq.storage_offset()).copy_(src2)
-                deliver(q, gq)
-        return (dx, dt if ctx.has_add else None, None) + tuple(grads.get(id(q)) for q in p.params)
+                torch.as_strided(gq, (cnt,), (1,), gq.storage_offset()).copy_(flat)
+            else:
+                gq = flat.clone()
+            deliver(q, gq)
+        for v, o, rows, cols, sstr_, q in p.targets2d:
+            gq = ops.padded_weight_like(q.shape, dev)
+            cols = min(cols, ops.weight_wcs(gq))
+            src2 = torch.as_strided(p.gv[v], (rows, cols), (sstr_, 1), o)
+            torch.as_strided(gq, (rows, cols), (ops.weight_wcs(gq), 1), gq.storage_offset()).copy_(src2)
+            deliver(q, gq)
+    return (dx, dt if ctx.has_add else None, None) + tuple(grads.get(id(q)) for q in p.params)
+
+
+class _Rec:
+    """Per-unit stand-in for an autograd context inside _PrepassFn.backward (what _backward_g reads)."""
+    __slots__ = ('plan', 'synced', 'has_dw', 'has_add', 'saved_tensors', 'needs_input_grad')
+
+
+class _PrepassFn(torch.autograd.Function):
+    """SEVERAL independent units as ONE autograd node (the gamma|beta nets of all SPADE layers of a generator: they read only the segmentation
+    map, reference inception_modules.py:746-762).  Forward and backward run the units in lockstep (_drive_many): the k-th SynchronizedBatchNorm
+    statistics exchanges of all units are one collective -- two per pass instead of two per unit -- and, being one node, the backward runs when
+    the gradients of ALL outputs are there, so its exchanges batch the same way.  Arithmetic per unit is unchanged (bit-identical results)."""
+
+    @staticmethod
+    def forward(ctx, plans, nparams, *args):
+        n = len(plans)
+        xs = [ops.conform(t) for t in args[:n]]
+        saves = [dict() for _ in plans]
+        ys = _drive_many([forward_g(p, x, None, sv) for p, x, sv in zip(plans, xs, saves)])
+        ctx.plans, ctx.nparams = plans, nparams
+        ctx.synced = ops.bn_sync() is not None
+        ctx.layout, tensors = [], []
+        for x, sv in zip(xs, saves):
+            t = [x, sv['z1'], sv['st1'][0], sv['st1'][1]]
+            if sv['zd'] is not None:
+                t += [sv['zd'], sv['std'][0], sv['std'][1]]
+            ctx.layout.append(len(t))
+            tensors += t
+        ctx.save_for_backward(*tensors)
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        saved, recs, o = ctx.saved_tensors, [], 0
+        for p, cnt in zip(ctx.plans, ctx.layout):
+            r = _Rec()
+            r.plan, r.synced, r.has_dw, r.has_add = p, ctx.synced, cnt == 7, False
+            r.saved_tensors, r.needs_input_grad = saved[o:o + cnt], (False, False)
+            o += cnt
+            recs.append(r)
+        outs = _drive_many([_backward_g(r, dy) for r, dy in zip(recs, dys)])
+        grads = []
+        for out in outs:
+            grads += list(out[3:])
+        return (None, None) + (None,) * len(ctx.plans) + tuple(grads)
+
+
+_PREPASS = os.environ.get('CAT_FUSED_SPADE_PREPASS', '1') != '0'      # A/B switch (round 5)
+
+
+def set_prepass(on):
+    global _PREPASS
+    old, _PREPASS = _PREPASS, bool(on)
+    return old
+
+
+def prepass(units):
+    """units: [(owner, res_ops, dw_ops, cin, cout, x)] of independent train-mode units whose input needs no gradient (gamma|beta nets on
+    the segmentation pyramid).  Returns their outputs, computed in lockstep with merged statistics exchanges, or None if that does not apply
+    (no multi-rank reducer, switch off, a unit the fused path does not take): the caller then runs the units one by one as before."""
+    if not _PREPASS or ops.bn_sync() is None or not _SYNC_FUSED or _UNITS not in ('all', 'gb') or len(units) < 2:
+        return None
+    xs = [ops.conform(u[5]) for u in units]
+    if any(x.requires_grad for x in xs) or not all(applicable(u[1], u[2], x, True) for u, x in zip(units, xs)):
+        return None
+    plans = tuple(plan_for(u[0], '_cat_fused_gb', u[1], u[2], u[3], u[4], x) for u, x in zip(units, xs))
+    STATS['prepass'] = STATS.get('prepass', 0) + 1
+    if not torch.is_grad_enabled():
+        return _drive_many([forward_g(p, x, None, None) for p, x in zip(plans, xs)])
+    params = [q for p in plans for q in p.params]
+    return list(_PrepassFn.apply(plans, tuple(len(p.params) for p in plans), *xs, *params))
 
 
 def apply(owner, slot, res_ops, dw_ops, cin, cout, x, addend=None):

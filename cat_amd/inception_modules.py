@@ -357,7 +357,10 @@ class InceptionSPADE(nn.Module):
         if not branch_ops:      # gamma = beta = 0: the plain param-free norm
             return pfn(x, fuse_act=fuse_act)
         from . import fused_spade
-        if fused_spade._UNITS in ('all', 'gb') and fused_spade.applicable(self.res_ops, self.dw_ops, seg, self.training):
+        pre = self.__dict__.pop('_cat_gb_pre', None)      # computed by the generator's pre-pass (all SPADE layers in lockstep, N > 1 ranks)
+        if pre is not None and tuple(pre.shape[2:]) == tuple(seg.shape[2:]):
+            gb = pre
+        elif fused_spade._UNITS in ('all', 'gb') and fused_spade.applicable(self.res_ops, self.dw_ops, seg, self.training):
             # all first convs / norms / depthwise convs / the 2C-channel branch sum of the gamma|beta net as 5 launches (cat_amd/fused_spade.py)
             gb = fused_spade.apply(self, '_cat_fused_gb', self.res_ops, self.dw_ops, self.input_dim, 2 * self.output_dim, seg)
         else:

@@ -59,6 +59,7 @@ class InceptionSPADEGenerator(BaseNetwork):
                     self.__dict__['_cat_prep_gen'] = fused_spade.PLAN_GEN
         seg = ops.conform(input)
         ret_acts = {}
+        self._gb_prepass(seg)
 
         def keep(name, t):
             """Tap `t` for the distillation loss; returns the tensor the network continues with (two consumers -> FanoutFn)."""
@@ -86,6 +87,42 @@ class InceptionSPADEGenerator(BaseNetwork):
             x = keep('up_4', self.up_4(x, seg))
         x = self.conv_img(self._lrelu(x), fuse_act=self._tanh)      # F.leaky_relu(x, 2e-1) -> conv_img -> tanh (:117-118)
         return (x, ret_acts) if len(mapping_layers) else x
+
+    def _block_sizes(self):
+        """(block name, spatial size its SPADE layer runs at), in forward order (the up-sampling schedule of forward())."""
+        h, w = self.sh, self.sw
+        out = [('head_0', (h, w))]
+        h, w = 2 * h, 2 * w
+        out.append(('G_middle_0', (h, w)))
+        if self.opt.num_upsampling_layers in ('more', 'most'):
+            h, w = 2 * h, 2 * w
+        out.append(('G_middle_1', (h, w)))
+        for name in ('up_0', 'up_1', 'up_2', 'up_3'):
+            h, w = 2 * h, 2 * w
+            out.append((name, (h, w)))
+        if self.opt.num_upsampling_layers == 'most':
+            out.append(('up_4', (2 * h, 2 * w)))
+        return out
+
+    def _gb_prepass(self, seg):
+        """Under SynchronizedBatchNorm over several ranks: the gamma|beta nets of ALL SPADE layers read only the segmentation map (reference
+        inception_modules.py:746-762), so they run first, in lockstep, with their statistics exchanges merged -- two collectives per pass
+        instead of two per layer (fused_spade.prepass); every InceptionSPADE then finds its [gamma | beta] ready.  A no-op on one rank."""
+        if not self.training or ops.bn_sync() is None:
+            return
+        from . import fused_spade
+        units, owners = [], []
+        for name, size in self._block_sizes():
+            sp = getattr(self, name).spade
+            sp.__dict__.pop('_cat_gb_pre', None)
+            if len(sp.res_ops) + len(sp.dw_ops) == 0:
+                continue
+            units.append((sp, sp.res_ops, sp.dw_ops, sp.input_dim, 2 * sp.output_dim, seg_at(seg, size)))
+            owners.append(sp)
+        gbs = fused_spade.prepass(units)
+        if gbs is not None:
+            for sp, gb in zip(owners, gbs):
+                sp.__dict__['_cat_gb_pre'] = gb
 
     def remove_spectral_norm(self):
         """Reference inception_spade_generator.py:126-137 (export path)."""

@@ -190,6 +190,20 @@ class DataParallelReducer:
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
+    def all_reduce_sum_many_(self, tensors):
+        """Several small statistics buffers as ONE collective (the lockstep units of fused_spade.prepass): flattened into one message and
+        scattered back -- element-wise sums, so every buffer ends up exactly as after its own all_reduce_sum_."""
+        if len(tensors) == 1:
+            return self.all_reduce_sum_(tensors[0])
+        flat = torch.cat([t.reshape(-1) for t in tensors])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        o = 0
+        for t in tensors:
+            n = t.numel()
+            t.copy_(flat[o:o + n].view_as(t))
+            o += n
+        return tensors
+
     def max_over_ranks(self, seconds):
         t = torch.tensor([seconds], dtype=torch.float64, device='cuda' if dist.get_backend(self.group) == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
