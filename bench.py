@@ -515,7 +515,7 @@ def student_forward_rate(model, batch, spade, graph=True):
             'batch': int(x.shape[0])}
 
 
-PROFILE_TAG = 'r04'
+PROFILE_TAG = 'r05'
 PMC_FILE = f'profiles/{PROFILE_TAG}_pmc_hbm.json'
 STATS_FILE = f'profiles/{PROFILE_TAG}_kernel_stats_c2.txt'
 META_FILE = f'profiles/{PROFILE_TAG}_meta.json'          # {"commit": ..., "date": ...}: the tree the committed profiles were taken from

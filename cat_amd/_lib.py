@@ -55,7 +55,7 @@ class QPlan(C.Structure):
 
 
 TNORM_MAXSLICE, DWM_MAXQ, PREP_MAXSRC = 8, 24, 8
-DWM_MAXQ_BWD = 16
+DWM_MAXQ_BWD = 18
 
 
 class NSlice(C.Structure):

@@ -357,7 +357,7 @@ int cat_affine_res_fwd(const float* x, int xcs, const float* scale, const float*
  * launch over channel slices: input = first-stage pre-norm buffer with that stage's scale / shift + activation applied while staging,
  * output = concatenated pre-norm buffer + its per-tile statistics.  w25: [25][4*nq] filters embedded in a 5 x 5 frame (cat_prep_run). */
 #define CAT_DWM_MAXQ 24      /* channel quads of the fused depthwise stage, forward (96 channels: 101 KB of LDS) */
-#define CAT_DWM_MAXQ_BWD 16  /* ... and of cat_dwm_bwd (two patches in LDS: 64 channels = 129 KB) */
+#define CAT_DWM_MAXQ_BWD 18  /* ... and of cat_dwm_bwd (two patches in LDS: 72 channels = 142 KB -- the unpruned gamma|beta nets, 3 x 21 -> 72) */
 typedef struct {
   int N, H, W;
   int nq;               /* channel quads */
