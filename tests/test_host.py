@@ -279,3 +279,49 @@ def test_split_bf16_emulation_properties():
         y = m.combine(lambda u, v: F.conv2d(u, v), a, w)
         err[terms] = float(((y.double() - exact).abs() / scale).max())
     assert 2.0 ** -12 < err[1] < 2.0 ** -7 and err[3] < 2.0 ** -15 and err[6] < 2.0 ** -20 and err[6] < err[3] < err[1], err
+
+
+def test_lockstep_driver_merges_the_kth_exchanges():
+    """fused_spade._drive / _drive_many (round 5): unit forwards / backwards are generators that yield the buffer of each statistics exchange.
+    _drive performs every exchange on the spot; _drive_many advances several independent units in lockstep and sends their k-th exchanges as ONE
+    collective -- units with fewer exchanges simply finish earlier.  Pure host logic: checked with stand-in generators and a recording reducer."""
+    import torch
+    from cat_amd import fused_spade, ops
+
+    class Recorder:
+        world_size = 2
+
+        def __init__(self):
+            self.calls = []
+
+        def all_reduce_sum_(self, t):
+            self.calls.append([t])
+            return t.mul_(2.0)
+
+        def all_reduce_sum_many_(self, ts):
+            self.calls.append(list(ts))
+            for t in ts:
+                t.mul_(2.0)
+            return ts
+
+    def unit(tag, nexch):
+        total = 0.0
+        for k in range(nexch):
+            buf = torch.full((3,), float(10 * tag + k))
+            yield buf
+            total += float(buf.sum())          # the reduced values are what the unit continues with
+        return tag, total
+
+    rec = Recorder()
+    ops.set_bn_sync(rec)
+    try:
+        before = fused_spade.STATS['collectives']
+        assert fused_spade._drive(unit(1, 2)) == (1, 2 * 3 * (10 + 11))
+        assert [len(c) for c in rec.calls] == [1, 1] and fused_spade.STATS['collectives'] == before + 2
+        rec.calls.clear()
+        res = fused_spade._drive_many([unit(1, 2), unit(2, 1), unit(3, 2), unit(4, 0)])
+        assert res == [(1, 2 * 3 * 21.0), (2, 2 * 3 * 20.0), (3, 2 * 3 * 61.0), (4, 0.0)]
+        assert [len(c) for c in rec.calls] == [3, 2]                       # first exchanges of units 1, 2, 3 together; second ones of 1 and 3
+        assert fused_spade.STATS['collectives'] == before + 4
+    finally:
+        ops.set_bn_sync(None)

@@ -46,6 +46,19 @@ def _worker(rank, world, port, q):
     assert torch.equal(fo.b[0], torch.full((5,), 3.0)) and torch.equal(fo.b[1], torch.arange(4, dtype=torch.float32) * 3)
     assert fo.grad_scale == 0.5
 
+    # 1b. several statistics buffers as ONE collective (the lockstep units of fused_spade.prepass): every buffer ends up exactly as after
+    #     its own all_reduce_sum_, shapes and views preserved
+    bufs = [torch.arange(6, dtype=torch.float32).reshape(2, 3) * (rank + 1), torch.full((5,), 0.25 * (rank + 1)), torch.ones(1) * rank]
+    singles = [b.clone() for b in bufs]
+    wide = torch.zeros(10)
+    view = wide[2:7]
+    view.copy_(bufs[1])
+    red.all_reduce_sum_many_([bufs[0], view, bufs[2]])
+    for t in singles:
+        red.all_reduce_sum_(t)
+    assert torch.equal(bufs[0], singles[0]) and torch.equal(view, singles[1]) and torch.equal(bufs[2], singles[2])
+    assert float(wide[:2].abs().sum()) == 0.0 and float(wide[7:].abs().sum()) == 0.0
+
     # 2. DataParallel loss semantics on a 2-shard batch (InstanceNorm config: only KA is shard dependent)
     g = H.load('step_in.npz')
     opt = H.make_opt(norm='instance', track=False, ndf=64)
