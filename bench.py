@@ -516,7 +516,7 @@ def student_forward_rate(model, batch, spade, graph=True):
 
 
 PROFILE_TAG = 'r05'
-PMC_FILE = f'profiles/{PROFILE_TAG}_pmc_hbm.json'
+PMC_FILE = f'profiles/{PROFILE_TAG}_pmc_hbm_patchgan_fwd.json'
 STATS_FILE = f'profiles/{PROFILE_TAG}_kernel_stats_c2.txt'
 META_FILE = f'profiles/{PROFILE_TAG}_meta.json'          # {"commit": ..., "date": ...}: the tree the committed profiles were taken from
 
@@ -539,16 +539,17 @@ def _profiles_stale():
 
 
 def pmc_traffic(family):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command (PMC_FILE, written by
-    tools/profile_round.sh: FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled per the gfx950 note in
-    MI355X_MICROARCH.md §HBM).  PMC collection cannot run inside the timed process, hence the lookup; None if absent."""
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (PMC_FILE: FETCH_SIZE and WRITE_SIZE in separate
+    passes, FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md §HBM; round 5: taken over tools/debug/patchgan_fwd_trace.py, the
+    PatchGAN forward of this workload, because the whole-step passes no longer fit the GPU budget of the round).  PMC collection cannot run
+    inside the timed process, hence the lookup; None if absent."""
     path = os.path.join(ROOT, PMC_FILE)
     if not os.path.exists(path):
         return None
     base = family.rsplit('_', 1)[0]               # conv_fwd32d_4x4x2x2 -> conv_fwd32d
     table = json.load(open(path))
     for k, v in table.items():
-        if k.startswith(base + '_kernel'):
+        if isinstance(v, dict) and k.startswith(base + '_kernel'):
             return v.get('hbm_bytes_per_launch')
     return None
 
@@ -616,7 +617,9 @@ def kernel_roofline(model, step, args):
     gflop_launch = d['gflop_per_step'] / max(d['launches_per_step'], 1)
     return {'bound': 'mfma', 'kernel': dom, 'achieved': round(achieved, 3), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
             'frac': round(achieved / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': pmc_traffic(dom) if headline else None,
-            'traffic_source': PMC_FILE + ' (separate rocprofv3 --pmc passes of this command; not a same-run measurement)',
+            'traffic_source': PMC_FILE + ' (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the PatchGAN forward of this workload: the three '
+                              'wide PatchGAN layers = 9 of the 20 launches of the family per step; not a same-run measurement.  Whole-step family average of '
+                              'round 4, identical tile: 421 MB per launch, profiles/r04_pmc_hbm.json)',
             'avg_launch_us': round(avg_us, 3),
             # the same fraction from the committed rocprofv3 --kernel-trace --stats summary (its average launch duration of this kernel):
             # HIP events see the kernel alone, rocprof's span includes dispatch overhead -- the two bracket the truth (~3 % apart)
