@@ -841,6 +841,7 @@ class _PrepassFn(torch.autograd.Function):
             ctx.layout.append(len(t))
             tensors += t
         ctx.save_for_backward(*tensors)
+        ctx.out_nhwc = [(y.shape[0], y.shape[2], y.shape[3], ops.act_cs(y)) for y in ys]
         return tuple(ys)
 
     @staticmethod
@@ -852,6 +853,9 @@ class _PrepassFn(torch.autograd.Function):
             r.saved_tensors, r.needs_input_grad = saved[o:o + cnt], (False, False)
             o += cnt
             recs.append(r)
+        # an output nobody used arrives as None: its unit still has to step through the lockstep exchanges (every rank does the same)
+        dys = [dy if dy is not None else torch.zeros(shape, device=saved[0].device, dtype=torch.float32).permute(0, 3, 1, 2)
+               for dy, shape in zip(dys, ctx.out_nhwc)]
         outs = _drive_many([_backward_g(r, dy) for r, dy in zip(recs, dys)])
         grads = []
         for out in outs:

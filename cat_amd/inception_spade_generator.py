@@ -113,10 +113,11 @@ class InceptionSPADEGenerator(BaseNetwork):
         from . import fused_spade
         units, owners = [], []
         for name, size in self._block_sizes():
-            sp = getattr(self, name).spade
+            blk = getattr(self, name)
+            sp = blk.spade
             sp.__dict__.pop('_cat_gb_pre', None)
-            if len(sp.res_ops) + len(sp.dw_ops) == 0:
-                continue
+            if len(sp.res_ops) + len(sp.dw_ops) == 0 or len(blk.res_ops) + len(blk.dw_ops) == 0:
+                continue      # no gamma|beta net, or a block pruned down to its shortcut (its SPADE layer never runs)
             units.append((sp, sp.res_ops, sp.dw_ops, sp.input_dim, 2 * sp.output_dim, seg_at(seg, size)))
             owners.append(sp)
         gbs = fused_spade.prepass(units)

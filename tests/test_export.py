@@ -172,3 +172,27 @@ def test_spade_twin_equals_the_hip_forward():
         y_hip = G(ops.to_nhwc(sem.cuda())).float().cpu()
         y_twin = twin(sem)
     assert H.rel_err(y_hip.numpy(), y_twin.numpy()) < TOL
+
+
+def test_spade_block_sizes_match_the_forward_schedule():
+    """InceptionSPADEGenerator._block_sizes (the resolutions the gamma|beta pre-pass prepares the segmentation pyramid at, round 5) against the
+    resolutions the SPADE layers actually run at -- observed on the host twin of the same generator with forward pre-hooks."""
+    from cat_amd import export
+    g, opt = _spade_fixture()
+    for ups in ('normal', 'more', 'most'):
+        o = Namespace(**vars(opt))
+        o.num_upsampling_layers = ups
+        from cat_amd import networks
+        o.ngf, o.norm_G = 4, 'spadesyncbatch3x3'
+        G = networks.define_G(opt.input_nc, 3, 4, 'inception_spade', 'instance', 0, 'xavier', 0.02, [], opt=o).eval()
+        twin = export.to_reference_module(G)
+        seen = {}
+        for name, _ in G._block_sizes():
+            getattr(twin, name).spade.register_forward_pre_hook(lambda m, a, name=name: seen.__setitem__(name, tuple(a[0].shape[2:])))
+        h = G.sh * (2 ** {'normal': 5, 'more': 6, 'most': 7}[ups])
+        w = G.sw * (2 ** {'normal': 5, 'more': 6, 'most': 7}[ups])
+        with torch.no_grad():
+            y = twin(torch.zeros(1, opt.input_nc + (0 if getattr(opt, 'no_instance', False) else 1), h, w))
+        want = {k: v for k, v in G._block_sizes() if len(getattr(G, k).res_ops) + len(getattr(G, k).dw_ops)}      # a block without branches skips its SPADE layer
+        assert want == seen and len(seen) >= 6, (ups, G._block_sizes(), seen)
+        assert tuple(y.shape[2:]) == (h, w)

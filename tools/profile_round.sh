@@ -2,6 +2,10 @@
 # Run ON THE GPU BOX (through gpurun) from the repo root: the round's measured artefacts -> gpurun_out/round/
 #   bench lines (c2 default incl. roofline + cpu_baseline, spade), rocprofv3 kernel-trace stats of the same commands,
 #   PMC passes (FETCH_SIZE / WRITE_SIZE separately, kernel-trace only -- never combined with sys/hip traces).
+# ROUND 5 NOTE: the whole-step PMC passes (FETCH_SIZE, WRITE_SIZE, SQ_*) take ~10 minutes EACH on this pool; the full script ran into a
+# 50-minute limit with nothing copied back.  They are therefore opt-in (WITH_PMC=1, give gpurun --timeout 4500); without it this script takes
+# ~8 minutes.  tools/profile_quick.sh + tools/debug/patchgan_fwd_trace.py are the 3-minute fallback the round's evidence was taken with.
+[ -z "$WITH_PMC" ] && SKIP_PMC=1
 set -x
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/round
