@@ -139,3 +139,42 @@ def test_load_pretrained_weight_spade_bit_exact():
     for key in g.files:
         if key.startswith('B:'):
             np.testing.assert_array_equal(sd[key[2:]].numpy(), g[key])
+
+
+def test_survey_canonical_students_are_reproduced():
+    """SURVEY section 8(d)'s canonical synthetic nets, built with cat_amd's own define_G / shrink search on the host: teacher
+    `define_G(3, 3, 64, 'inception_9blocks', ...)` after torch.manual_seed(233), every norm weight overwritten with |N(0, 1)| drawn in module order
+    from torch.Generator().manual_seed(7), pruned to the launch scripts' budgets with prune_cin_lb = 16.  S_2.6 (InstanceNorm, 2.6e9): threshold,
+    n_macs and every channel list are the ones the survey's probe of the REFERENCE printed; S_4.6 (BatchNorm, 4.6e9): the channel lists are
+    (its threshold / n_macs read 0.9490039 / 4 591 284 224 here against 0.9516321 / 4 586 242 048 in the survey's text, with identical
+    structure -- the survey's own conv-MAC figure for this student, 4 591.3 M, is the number found here).  bench.py draws the norm scales from
+    the platform-independent PCG64 stream instead: same recipe, trunk 77 instead of 82."""
+    import copy
+    from cat_amd import networks, prune
+
+    def canonical(norm, track, target):
+        opt = H.make_opt(norm=norm, track=track, target_flops=target, prune_cin_lb=16)
+        torch.manual_seed(233)
+        T = networks.define_G(3, 3, 64, 'inception_9blocks', norm, 0, 'normal', 0.02, [], opt=opt)
+        gen = torch.Generator().manual_seed(7)
+        with torch.no_grad():
+            for m in T.modules():
+                if isinstance(m, (torch.nn.BatchNorm2d, torch.nn.InstanceNorm2d)) and getattr(m, 'weight', None) is not None:
+                    m.weight.copy_(torch.randn(m.weight.shape, generator=gen).abs())
+        T.eval()
+        thr, searched = prune.search_threshold(T, target, opt)
+        S = copy.deepcopy(T)
+        prune._apply_structure(S, T, thr, opt, copy_weights=True)
+        macs, _ = prune.model_profiling(S, 256, 256)
+        return float(thr), searched, macs, S
+
+    thr, searched, macs, S = canonical('instance', False, 2.6e9)
+    assert '%.7f' % thr == '1.1518520' and searched == macs == 2566197248
+    assert [S.down_sampling[i].num_features for i in (2, 5, 8)] == [16, 25, 56] and [S.up_sampling[i].num_features for i in (1, 4)] == [30, 16]
+    want = [([11, 14, 10], [8, 12, 11]), ([11, 11, 11], [14, 7, 11]), ([6, 15, 10], [13, 11, 9]), ([11, 7, 11], [14, 12, 11]), ([4, 13, 15], [10, 16, 10]),
+            ([11, 7, 9], [10, 10, 9]), ([7, 10, 7], [14, 9, 8]), ([7, 10, 8], [10, 9, 6]), ([7, 9, 9], [14, 10, 10])]
+    assert [(b.res_channels, b.dw_channels) for b in S.features] == want
+    thr, searched, macs, S = canonical('batch', True, 4.6e9)
+    assert searched == macs <= 4.6e9
+    assert [S.down_sampling[i].num_features for i in (2, 5, 8)] == [22, 37, 82] and [S.up_sampling[i].num_features for i in (1, 4)] == [38, 16]
+    assert (S.features[0].res_channels, S.features[0].dw_channels) == ([17, 17, 14], [12, 13, 15])
