@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libcat_hip.so')
-SOURCES = ['runtime.hip', 'conv_igemm.hip', 'conv_smallco.hip', 'conv_pk.hip', 'conv_q.hip', 'conv_split.hip', 'conv_twgrad.hip', 'conv_pwgrad.hip', 'block_norm.hip', 'dwconv.hip', 'norm.hip', 'elementwise.hip', 'ka_loss.hip', 'spade.hip', 'eval_ops.hip']
+SOURCES = ['runtime.hip', 'conv_igemm.hip', 'conv_smallco.hip', 'conv_pk.hip', 'conv_ksum.hip', 'conv_q.hip', 'conv_split.hip', 'conv_twgrad.hip', 'conv_pwgrad.hip', 'block_norm.hip', 'dwconv.hip', 'norm.hip', 'elementwise.hip', 'ka_loss.hip', 'spade.hip', 'eval_ops.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC']
 
 

@@ -37,6 +37,17 @@ class TConv(C.Structure):
                                                                                             ('seg', TSeg * TCONV_MAXSEG)]
 
 
+KSUM_MAXSEG = 4
+
+
+class KSeg(C.Structure):
+    _fields_ = [('src', c_p), ('w', c_p)] + [(n, c_i) for n in ('xcs', 'c4', 'cin', 'ks', 'reflect', 'wcs')]
+
+
+class KSum(C.Structure):
+    _fields_ = [(n, c_i) for n in ('N', 'H', 'W', 'Cout', 'ycs', 'ycw', 'rcs', 'act')] + [('slope', c_f), ('nseg', c_i), ('seg', KSeg * KSUM_MAXSEG)]
+
+
 QCONV_MAXSEG = 8
 
 
@@ -109,6 +120,8 @@ SIGNATURES = {
     'cat_tconv_pack_floats': (C.c_size_t, [c_i, c_i, c_i]),
     'cat_tconv_pack': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
     'cat_tconv_fwd': (c_i, [_TG, c_p, c_p, c_p, c_p]),
+    'cat_conv2d_ksum_supported': (c_i, [C.POINTER(KSum)]),
+    'cat_conv2d_ksum_fwd': (c_i, [C.POINTER(KSum), c_p, c_p, c_p, c_p]),
     'cat_tstage1_supported': (c_i, [c_i, c_i, c_i]),
     'cat_tstage1_fwd': (c_i, [C.POINTER(Stage1Geom), c_p, c_p, c_p, c_p, c_p, c_p]),
     'cat_tstage1_dgrad_supported': (c_i, [c_i, c_i, c_i]),
@@ -191,6 +204,11 @@ def lib_path():
         import sys
         print('cat_amd: loading the DIAGNOSTIC library (CAT_LIB=diag): timing experiments only, results may be intentionally wrong', file=sys.stderr)
         return _build.DIAG_LIB
+    alt = os.environ.get('CAT_LIB', '')
+    if alt.endswith('.so'):      # A/B timing of two builds of this library on one box (tools/debug/*): an explicit path, never a fallback
+        import sys
+        print(f'cat_amd: loading {alt} (CAT_LIB)', file=sys.stderr)
+        return alt
     return _build.LIB
 
 

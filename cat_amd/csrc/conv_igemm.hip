@@ -563,7 +563,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
-          for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][t], fb[j][t], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[j][t], fa[i][t], acc[i][j], 0, 0, 0);   // D^T: see the epilogue
     }
   };
   const int nk = taps * (p.c4 >> 5);
@@ -579,18 +579,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
   mma((nk - 1) & 1);
 
+  // The filter fragment went in as the MFMA's FIRST operand: the accumulators are transposed, lane (lr, lq) holds output channels
+  // j * 16 + lq * 4 + 0..3 of pixel i * 16 + lr -- one float4 store per tile instead of four scalar ones (round 6: -3.7 % on a 256 -> 256 3x3)
+  const bool vec = (p.ycs & 3) == 0 && (reinterpret_cast<uintptr_t>(p.out) & 15) == 0;
 #pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int col = n0 + wn * NT * 16 + j * 16 + lr;
-    const bool cvalid = col < p.Cout;
-    const float bias = (cvalid && p.bias) ? p.bias[col] : 0.f;
-    if (!cvalid && col >= p.cw) continue;
+  for (int i = 0; i < MT; ++i) {
+    const int m = m0 + wm * MT * 16 + i * 16 + lr;
+    if (m >= p.M) continue;
+    float* yo = p.out + (int64_t)m * p.ycs;
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
+    for (int j = 0; j < NT; ++j) {
+      const int c0 = n0 + wn * NT * 16 + j * 16 + lq * 4;
+      if (c0 >= p.cw) continue;
+      if (vec && c0 + 3 < p.Cout) {
+        f4 v = acc[i][j];
 #pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        const int m = m0 + wm * MT * 16 + i * 16 + lq * 4 + rg;
-        if (m < p.M) p.out[(int64_t)m * p.ycs + col] = cvalid ? cat::apply_act(acc[i][j][rg] + bias, p.act, p.slope) : 0.f;
+        for (int e = 0; e < 4; ++e) v[e] = cat::apply_act(v[e] + (p.bias ? p.bias[c0 + e] : 0.f), p.act, p.slope);
+        *reinterpret_cast<f4*>(yo + c0) = v;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int c = c0 + e;
+          if (c < p.Cout) yo[c] = cat::apply_act(acc[i][j][e] + (p.bias ? p.bias[c] : 0.f), p.act, p.slope);
+          else if (c < p.cw) yo[c] = 0.f;
+        }
       }
     }
   }
@@ -1158,7 +1170,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
-          for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][t], fb[j][t], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[j][t], fa[i][t], acc[i][j], 0, 0, 0);   // D^T: see the epilogue
     }
   };
   const int nk = ntaps * (p.c4 >> 5);
@@ -1175,23 +1187,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     mma((nk - 1) & 1);
   }
+  // transposed accumulators (filter fragment = the MFMA's first operand): lane (lr, lq) holds input channels j * 16 + lq * 4 + 0..3 of class
+  // pixel i * 16 + lr -- one pixel address and one float4 store per tile instead of four of each
+  const bool vec = (p.ocs & 3) == 0 && (reinterpret_cast<uintptr_t>(p.out) & 15) == 0;
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
+    const int m = m0 + wm * MT * 16 + i * 16 + lr;
+    if (m >= Mc) continue;
+    const int n = m / HcWc, rem = m - n * HcWc;
+    const int a = rem / Wc, b = rem - a * Wc;
+    float* orow = p.out + (((int64_t)n * p.Hin + (iyf + a * s)) * p.Win + (ixf + b * s)) * p.ocs;
 #pragma unroll
-    for (int rg = 0; rg < 4; ++rg) {
-      const int m = m0 + wm * MT * 16 + i * 16 + lq * 4 + rg;
-      if (m >= Mc) continue;
-      const int n = m / HcWc, rem = m - n * HcWc;
-      const int a = rem / Wc, b = rem - a * Wc;
-      float* orow = p.out + (((int64_t)n * p.Hin + (iyf + a * s)) * p.Win + (ixf + b * s)) * p.ocs;
+    for (int j = 0; j < NT; ++j) {
+      const int c0 = n0 + wn * NT * 16 + j * 16 + lq * 4;
+      if (c0 >= p.cw) continue;
+      if (vec && c0 + 3 < p.Cin) {
+        f4 v = acc[i][j];
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const int col = n0 + wn * NT * 16 + j * 16 + lr;
-        if (col < p.Cin) {
-          const float bias = p.bias ? p.bias[col] : 0.f;
-          orow[col] = cat::apply_act(acc[i][j][rg] + bias, p.act, p.slope);
-        } else if (col < p.cw) {
-          orow[col] = 0.f;
+        for (int e = 0; e < 4; ++e) v[e] = cat::apply_act(v[e] + (p.bias ? p.bias[c0 + e] : 0.f), p.act, p.slope);
+        *reinterpret_cast<f4*>(orow + c0) = v;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int c = c0 + e;
+          if (c < p.Cin) orow[c] = cat::apply_act(acc[i][j][e] + (p.bias ? p.bias[c] : 0.f), p.act, p.slope);
+          else if (c < p.cw) orow[c] = 0.f;
         }
       }
     }

@@ -166,7 +166,12 @@ def block_forward(block, x):
         outs = [fn(x) for fn in fns]
     if not fused_tail:
         return ops.AddNFn.apply(x, *outs)
-    from . import tconv
+    from . import ksum, tconv
+    refl = p['pad_mode'] == L.PAD_REFLECT
+    # wide output (the teacher's C = 256): the tail as ONE implicit GEMM on 128 x 128 tiles with both operands DMA-ed into LDS
+    ksegs = [ksum.Segment(outs[0], p['w_f'], False)] + [ksum.Segment(hid, wd['w2'], refl) for wd, hid in zip(p['wides'], outs[1:])]
+    if ksum.applicable(ksegs, n, h, w, c):
+        return ksum.run(ksegs, p['b_f'], ops.empty_act(n, c, h, w, x.device), res=x)
     if p['tail_pack'] is None:      # packed filters of the fused tail (once per plan): segment 0 = F, then one segment per wide branch
         packs = [tconv.pack(p['w_f'], tconv.FWD)] + [tconv.pack(wd['w2'], tconv.FWD) for wd in p['wides']]
         offs, po = [], 0
@@ -174,7 +179,6 @@ def block_forward(block, x):
             offs.append(po)
             po += pk.numel()
         p['tail_pack'], p['tail_offs'] = torch.cat(packs), offs
-    refl = p['pad_mode'] == L.PAD_REFLECT
     segs = [tconv.Segment(outs[0], 1, 0, False, p['tail_offs'][0])]
     for wd, hid, off in zip(p['wides'], outs[1:], p['tail_offs'][1:]):
         segs.append(tconv.Segment(hid, wd['k'], (wd['k'] - 1) // 2, refl, off))

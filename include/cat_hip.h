@@ -319,6 +319,36 @@ int cat_tconv_pack(const float* w, int mode, int Nn, int Ck, int ks, int wcs, in
 int cat_tconv_fwd(const cat_tconv_t* g, const float* pack, const float* bias, float* y, cat_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * K-concatenated SUM of stride-1 "same" convolutions (k in {1,3,5}, padding (k-1)/2, zero or reflect) over different tensors as ONE
+ * implicit GEMM on 128 x 128 output tiles with both operands DMA-ed into LDS (csrc/conv_ksum.hip):
+ *   y[n][oy][ox][co] = act(bias[co] + sum_s sum_(ky,kx) sum_c src_s[n][oy-pad_s+ky][ox-pad_s+kx][c] * w_s[co][ky][kx][c]) + res[n][oy][ox][co]
+ * Replaces, for the eval-mode (frozen, BatchNorm-folded) teacher, the tail of InvertedResidualChannels.forward
+ * (models/modules/inception_modules.py:230-236): the six second convs (the four 1 x 1 ones as one K = 176 segment), their sum, pw_bn and
+ * the skip connection -- torch: 6 x F.conv2d + 5 x aten::add + F.batch_norm + aten::add.  Filters are read in the product's own layout
+ * [Cout][k][k][wcs]; wide N (Cout >= 64) is what it is built for, the narrow layers stay on cat_tconv_fwd. */
+#define CAT_KSUM_MAXSEG 4
+typedef struct {
+  const float* src;    /* [N][H][W][xcs], pointing at the segment's first channel */
+  const float* w;      /* [Cout][ks][ks][wcs] */
+  int xcs, c4;         /* pixel stride of src, channels read per tap (multiple of 4; channels [cin, c4) must hold zeros or meet zero filters) */
+  int cin;             /* valid channels (<= c4): FLOP accounting only; 0 = c4 */
+  int ks;              /* ks x ks taps, padding (ks - 1) / 2 */
+  int reflect;         /* source pixels outside the plane: 1 = mirrored (nn.ReflectionPad2d), 0 = zero; one mode per launch */
+  int wcs;             /* floats per (output channel, tap) of w (multiple of 4, >= c4) */
+} cat_ksum_seg_t;
+typedef struct {
+  int N, H, W;         /* planes (input = output size) */
+  int Cout, ycs, ycw;  /* output channels, pixel stride, channels [Cout, ycw) are written as 0 */
+  int rcs;             /* pixel stride of res */
+  int act;             /* epilogue activation (before the residual) */
+  float slope;
+  int nseg;
+  cat_ksum_seg_t seg[CAT_KSUM_MAXSEG];
+} cat_ksum_t;
+int cat_conv2d_ksum_supported(const cat_ksum_t* g);
+int cat_conv2d_ksum_fwd(const cat_ksum_t* g, const float* bias, const float* res, float* y, cat_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
  * Train-mode norm layers of an InvertedResidualChannels block without their own passes (csrc/block_norm.hip): the producing
  * conv leaves per-tile statistics (cat_tconv_fwd `stats`, cat_dwm_fwd), cat_tnorm_finalize turns the table of ALL branches of a
  * block stage into scale / shift (+ running statistics of every branch's nn.BatchNorm2d, inception_modules.py:43-44,150-173), and
