@@ -392,7 +392,7 @@ def _finalize_g(p, part, scs, n, h, w, gamma, beta, pairs):
         L.call('cat_tnorm_finalize', ops._p(part), scs, 1, n, h, w, ops._p(gamma), ops._p(beta), len(pairs), _slices(pairs), p.eps, p.momentum,
                ops._p(ss[0]), ops._p(ss[1]), ops._p(mr[0]), ops._p(mr[1]), scs, ops._stream())
         return ss, mr
-    sums = torch.empty(2 * scs, device=part.device, dtype=torch.float32)
+    sums = yield Alloc(2 * scs, part.device)      # a slice of the round's arena under _drive_many: the merged exchange needs no pack / unpack
     L.call('cat_tnorm_sums', ops._p(part), scs, n, h, w, 8, 16, 1, ops._p(sums), ops._stream())
     yield sums
     count = float(n * h * w) * sync.world_size
@@ -401,11 +401,24 @@ def _finalize_g(p, part, scs, n, h, w, gamma, beta, pairs):
     return ss, mr
 
 
+class Alloc:
+    """A unit generator's request for the buffer of its next statistics exchange (n floats, n % 4 == 0).  `_drive_many` hands every unit of
+    a lockstep round a slice of ONE arena, in unit order, so that the round's exchanges are one contiguous message: the collective runs on
+    the arena itself, without the torch.cat / copy_ kernels a pack + unpack would launch (round-5 verdict, robustness #15)."""
+    __slots__ = ('n', 'device')
+
+    def __init__(self, n, device):
+        self.n, self.device = int(n), device
+
+
 def _drive(gen):
     """Run ONE unit generator to completion; every statistics exchange it asks for happens immediately (one collective each)."""
     try:
         req = next(gen)
         while True:
+            if isinstance(req, Alloc):
+                req = gen.send(torch.empty(req.n, device=req.device, dtype=torch.float32))
+                continue
             ops.bn_sync().all_reduce_sum_(req)
             STATS['collectives'] += 1
             req = gen.send(None)
@@ -415,7 +428,8 @@ def _drive(gen):
 
 def _drive_many(gens):
     """Run several INDEPENDENT unit generators in lockstep: the k-th exchanges of all of them travel as ONE collective (their buffers are
-    summed element-wise either way: results are bit-identical to `_drive` on each)."""
+    summed element-wise either way: the same arithmetic per element as `_drive` on each; the reduction order is the backend's).  Units that
+    ask for their buffer first (`Alloc`) get adjacent slices of one arena, and the collective is issued on the arena."""
     results, reqs = [None] * len(gens), {}
     for i, g in enumerate(gens):
         try:
@@ -423,6 +437,21 @@ def _drive_many(gens):
         except StopIteration as e:
             results[i] = e.value
     while reqs:
+        allocs = [i for i in sorted(reqs) if isinstance(reqs[i], Alloc)]
+        if allocs:
+            dev = reqs[allocs[0]].device
+            sizes = [(reqs[i].n + 3) // 4 * 4 for i in allocs]
+            arena = torch.empty(sum(sizes), device=dev, dtype=torch.float32)
+            o = 0
+            for i, sz in zip(allocs, sizes):
+                n = reqs[i].n
+                try:
+                    reqs[i] = gens[i].send(arena[o:o + n])
+                except StopIteration as e:
+                    results[i] = e.value
+                    del reqs[i]
+                o += sz
+            continue
         order = sorted(reqs)
         ops.bn_sync().all_reduce_sum_many_([reqs[i] for i in order])
         STATS['collectives'] += 1
@@ -575,7 +604,7 @@ def _norm_bwd_g(p, n, hw, c, cs, x, dy, gamma, beta, mr, dgamma, dbeta, synced=F
         if sync is None:
             raise RuntimeError('fused SPADE unit backward: the forward ran under a SynchronizedBatchNorm reducer that is gone')
         m = n * hw
-        sums = torch.empty(2 * cs, device=x.device, dtype=torch.float32)
+        sums = yield Alloc(2 * cs, x.device)
         ws = ops.workspace(L.query('cat_bn_ws_bytes', m, cs), x.device)
         st = ops._stream()
         L.call('cat_bn_stats_bwd', ops._p(x), ops._p(dy), ops._p(gamma), ops._p(beta), ops._p(mr[0]), ops._p(mr[1]), m, c, cs, p.act, p.slope,

@@ -195,6 +195,18 @@ class DataParallelReducer:
         scattered back -- element-wise sums, so every buffer ends up exactly as after its own all_reduce_sum_."""
         if len(tensors) == 1:
             return self.all_reduce_sum_(tensors[0])
+        # adjacent slices of one arena (what fused_spade._drive_many hands out): the collective runs on the arena span itself -- no
+        # torch.cat / copy_ kernels on the step (gaps are the arena's 16-byte alignment padding: summed along, never read)
+        first, ok = tensors[0], True
+        end = first.data_ptr() + 4 * first.numel()
+        for t in tensors[1:]:
+            ok = ok and t.is_contiguous() and t.dtype == first.dtype and t.device == first.device and \
+                t.untyped_storage().data_ptr() == first.untyped_storage().data_ptr() and end <= t.data_ptr() <= end + 12
+            end = t.data_ptr() + 4 * t.numel()
+        if ok and first.is_contiguous() and first.dtype == torch.float32:
+            span = torch.as_strided(first, ((end - first.data_ptr()) // 4,), (1,), first.storage_offset())
+            dist.all_reduce(span, op=dist.ReduceOp.SUM, group=self.group)
+            return tensors
         flat = torch.cat([t.reshape(-1) for t in tensors])
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
         o = 0

@@ -58,6 +58,23 @@ def _worker(rank, world, port, q):
         red.all_reduce_sum_(t)
     assert torch.equal(bufs[0], singles[0]) and torch.equal(view, singles[1]) and torch.equal(bufs[2], singles[2])
     assert float(wide[:2].abs().sum()) == 0.0 and float(wide[7:].abs().sum()) == 0.0
+    # 1c. adjacent slices of one arena (what fused_spade._drive_many hands out): reduced IN PLACE on the arena span -- no pack / unpack copies
+    #     (the arena's storage is what travels: its address must be the message's)
+    arena = torch.arange(24, dtype=torch.float32) * (rank + 1)
+    parts = [arena[0:8], arena[8:16], arena[16:24]]
+    seen = []
+    real_all_reduce = parallel.dist.all_reduce
+
+    def spy(t, *a, **k):
+        seen.append((t.data_ptr(), t.numel()))
+        return real_all_reduce(t, *a, **k)
+    parallel.dist.all_reduce = spy
+    try:
+        red.all_reduce_sum_many_(parts)
+    finally:
+        parallel.dist.all_reduce = real_all_reduce
+    assert seen == [(arena.data_ptr(), 24)], seen
+    assert torch.equal(arena, torch.arange(24, dtype=torch.float32) * 3)
 
     # 2. DataParallel loss semantics on a 2-shard batch (InstanceNorm config: only KA is shard dependent)
     g = H.load('step_in.npz')
