@@ -1595,9 +1595,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 
 // ------------------------------------------------------------------------------------------------ host side
 // N = 130 .. 192 (the frozen teacher's 176-wide fused GEMM, SPADE's 170-wide heads) fills two 96-wide tiles better than two 128-wide
-// ones (8 % instead of 31 % padding at 176).  Opt-in (CAT_TILE_BY_PAD=1) until the two variants have been timed against each other.
+// ones (8 % instead of 31 % padding at 176); kept switched off (`on`): the 176-wide layer is the frozen teacher's merged 1 x 1, served by the
+// direct-to-LDS 128 x 128 tile ahead of this dispatch.
 static bool prefer_96_wide(int n) {
-  static const int on = getenv("CAT_TILE_BY_PAD") ? atoi(getenv("CAT_TILE_BY_PAD")) : 0;
+  constexpr int on = 0;
   return on && n > 96 && (int64_t)cat::cdiv(n, 96) * 96 * 10 <= (int64_t)cat::cdiv(n, 128) * 128 * 9;
 }
 
@@ -1660,7 +1661,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 static int default_bm(int n) { return n <= 32 ? 256 : 128; }
 static bool use_small_m(int M, int n) {
-  static const int mode = getenv("CAT_SMALLM") ? atoi(getenv("CAT_SMALLM")) : 1;
+  constexpr int mode = 1;
   if (!mode || n > 32) return false;   // measured: helps the 16/32-wide tiles (256-row default), not the 48..96-wide ones
   return cdiv(M, default_bm(n)) < 768;
 }
@@ -1670,7 +1671,7 @@ static bool use_small_m(int M, int n) {
 struct SplitPlan { int ksplit, kchunks; };
 static SplitPlan split_plan(int M, int n, int nk) {
   SplitPlan p{1, nk};
-  static const int off = getenv("CAT_NO_SPLITK") ? atoi(getenv("CAT_NO_SPLITK")) : 0;
+  constexpr int off = 0;
   const bool smallm = use_small_m(M, n);
   const int bn = n <= 16 ? 16 : n <= 32 ? 32 : n <= 48 ? 48 : n <= 64 ? 64 : n <= 96 ? 96 : 128;
   const int bm = n > 96 ? 128 : (smallm ? (n <= 32 ? 128 : 64) : (n <= 32 ? 256 : 128));
@@ -1747,7 +1748,7 @@ WgradPlan wgrad_plan(const cat_conv_t* g) {
 extern "C" {
 
 static bool fwd_bk32_ok(const IgemmArgs& a) {
-  static const int no_bk32 = getenv("CAT_NO_BK32") ? atoi(getenv("CAT_NO_BK32")) : 0;
+  constexpr int no_bk32 = 0;
   static const bool dbg_on = cat::kDiag && getenv("CAT_DBG");
   return !no_bk32 && a.wvec && (a.c4 & 15) == 0 && !dbg_on;
 }
@@ -1983,7 +1984,7 @@ static int conv_dgrad_impl(const cat_conv_t* g, const float* dy, const float* w,
     return cat::smallci_dgrad(g, dy, w, dx, dxcs, a.cw, s);
   }
   // BK = 32 variant of the 128 x 128 tile (the discriminator's and the teacher's wide layers)
-  static const int bk32 = getenv("CAT_DGRAD_BK32") ? atoi(getenv("CAT_DGRAD_BK32")) : 1;
+  constexpr int bk32 = 1;
   if (bk32 && a.ksplit == 1 && dgrad32d_ok(g) && a.c4 == g->Cout) {
     cat::ProfScope prof(wt ? "conv_dgrad32dt_4x4x2x2" : "conv_dgrad32d_4x4x2x2", prof_flops, 0.0, stream);
     const dim3 grid(cdiv(mmax, 128) * cdiv(a.Cin, 128), st * st);
@@ -2015,7 +2016,7 @@ static int conv_dgrad_impl(const cat_conv_t* g, const float* dy, const float* w,
 static int wgrad32d_nsplit(const cat_conv_t* g, int* rows_per) {
   static const int on = getenv("CAT_WGRAD_DIRECT") ? atoi(getenv("CAT_WGRAD_DIRECT")) : 1;
   const int wcs = g->wcs > 0 ? g->wcs : g->Cin;
-  static const int ragged = getenv("CAT_WGRAD_RAGGED") ? atoi(getenv("CAT_WGRAD_RAGGED")) : 1;   // output rows that end in a partial 32-pixel segment
+  constexpr int ragged = 1;   // output rows that end in a partial 32-pixel segment
   if (!on || g->Cout <= 96 || (g->Cin & 127) || g->pad_mode != CAT_PAD_ZERO || (!ragged && g->Wo > 32 && (g->Wo & 31)) || cat::smallco_applicable(g) ||
       (int64_t)g->N * g->H * g->W * g->xcs * 4 >= (int64_t)2147483647 || (int64_t)g->N * g->Ho * g->Wo * g->ycs * 4 >= (int64_t)2147483647 ||
       wcs < g->Cin)

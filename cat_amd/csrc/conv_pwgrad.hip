@@ -108,7 +108,7 @@ namespace cat {
 static int pw_blocks(const cat_conv_t* g) {
   const int64_t P = (int64_t)g->N * g->H * g->W;
   const int groups = (((g->Cin + 3) & ~3) + 63) / 64;
-  static const int target = getenv("CAT_PWGRAD_BLOCKS") ? atoi(getenv("CAT_PWGRAD_BLOCKS")) : 1024;
+  constexpr int target = 1024;
   int64_t nb = target / groups;               // ~4 workgroups per CU over all channel groups
   const int64_t most = (P + 255) / 256;       // at least 256 pixels (8 steps) per workgroup
   if (nb > most) nb = most;

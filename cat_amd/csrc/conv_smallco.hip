@@ -368,7 +368,7 @@ static bool fwd_small_image(const cat_conv_t* g) { return g->Cin >= 64 && (int64
 // PatchGAN's head at batch 16 is 64 workgroups walking 32 channel chunks each: with a workspace the channel range is cut into
 // slices of >= 2 chunks (8 quads each) until ~512 workgroups exist
 int smallco_fwd_ksplit(const cat_conv_t* g) {
-  static const int on = getenv("CAT_SMALLCO_SPLITK") ? atoi(getenv("CAT_SMALLCO_SPLITK")) : 1;
+  constexpr int on = 1;
   if (!on || !fwd_small_image(g)) return 1;
   const int blocks = g->N * cdiv(g->Ho, 8) * cdiv(g->Wo, 32);
   const int chunks = cdiv(((g->Cin + 3) & ~3) / 4, 8);

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void dw_dgrad_kernel(DwArgs p, int Hin, int Wi
 
 // dw[c][tap] partials: lanes = (pixel-lane, channel quad); each lane keeps one float4 accumulator per tap of ONE filter row
 // (blockIdx.y = ky) to bound registers at kw*4; block-reduced through LDS; partial [nb][taps][cs] in ws.
-// IT = index type of the pixel walk (int64_t, or int with CAT_IDX32=1 when N*Ho*Wo < 2^31: the two div/mods per pixel are emulated at 64 bits)
+// IT = index type of the pixel walk (int64_t; the int instantiation is kept switched off -- `idx32_on` -- when N*Ho*Wo < 2^31: the two div/mods per pixel are emulated at 64 bits)
 template <int KW, typename IT>
 __global__ __launch_bounds__(256) void dw_wgrad_kernel(DwArgs p, float* __restrict__ part, int nb, int ppl) {
   __shared__ f4 red[256];
@@ -234,7 +234,7 @@ int cat_dwconv2d_wgrad(const cat_conv_t* g, const float* x, const float* dy, flo
   hipStream_t s = (hipStream_t)stream;
   cat::ProfScope prof("dwconv_wgrad", 2.0 * g->N * g->Ho * g->Wo * g->Cin * g->kh * g->kw, 2 * 4.0 * (double)g->N * g->Ho * g->Wo * g->ycs, stream);
   dim3 grid(pl.nb, g->kh);
-  static const int idx32_on = getenv("CAT_IDX32") ? atoi(getenv("CAT_IDX32")) : 0;
+  constexpr int idx32_on = 0;
   const bool i32 = idx32_on && (int64_t)g->N * g->Ho * g->Wo < (int64_t)2147483647 - 65536;
 #define DW_WGRAD(KW)                                                                             \
   if (i32) dw_wgrad_kernel<KW, int><<<grid, 256, 0, s>>>(a, (float*)ws, pl.nb, pl.ppl);          \

@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void norm_fwd_finalize_kernel(const float* __r
 }
 
 // y = act(x * scale[g][c] + shift[g][c]); scale/shift hold zeros on padding channels.
-// IT = index type of the element walk: int64_t, or int (opt-in, CAT_IDX32=1) when the tensor has < 2^31 quads -- the `%` and `/` below are
+// IT = index type of the element walk: int64_t, or int (kept switched off: `idx32`'s `on`) when the tensor has < 2^31 quads -- the `%` and `/` below are
 // emulated in ~100 instructions each at 64 bits, which is most of what these HBM-bound kernels execute per float4.
 template <typename IT>
 __global__ __launch_bounds__(256) void norm_apply_kernel(const float* __restrict__ x, const float* __restrict__ scale,
@@ -217,6 +217,28 @@ __global__ __launch_bounds__(256) void norm_bwd_finalize_kernel(const float* __r
     if (dgamma) dgamma[c] = accumulate ? dgamma[c] + s1 : s1;
     if (dbeta) dbeta[c] = accumulate ? dbeta[c] + s0 : s0;
   }
+}
+
+// nn.InstanceNorm2d(track_running_stats=True).train() (models/networks.py:29-64 with --norm instance --norm_track_running_stats): torch
+// feeds the instances to batch_norm as N * C channels and averages the per-instance updates over the batch, i.e.
+//   running_mean[c] = (1 - m) * running_mean[c] + m * mean_n(mean[n][c]),  running_var[c] likewise with the UNBIASED per-instance variance
+// (recovered from the saved rstd: var = 1 / rstd^2 - eps).
+__global__ __launch_bounds__(256) void in_running_kernel(const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                         float* __restrict__ running_mean, float* __restrict__ running_var, int G, int Pg,
+                                                         int C, float eps, float momentum, int64_t* __restrict__ num_batches) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (num_batches && c == 0) *num_batches += 1;
+  if (c >= C) return;
+  float sm = 0.f, sv = 0.f;
+  for (int g = 0; g < G; ++g) {
+    const float r = rstd[g * C + c];
+    float var = 1.f / (r * r) - eps;
+    var = var > 0.f ? var : 0.f;
+    sm += mean[g * C + c];
+    sv += Pg > 1 ? var * (float)Pg / (float)(Pg - 1) : var;
+  }
+  running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (sm / (float)G);
+  running_var[c] = (1.f - momentum) * running_var[c] + momentum * (sv / (float)G);
 }
 
 // dgamma[c] (+)= sum_g sum(g*xhat), dbeta[c] (+)= sum_g sum(g)  (sums recovered from the per-group means)
@@ -396,7 +418,7 @@ int ew_grid(int64_t n) {
 
 // 32-bit element walk (opt-in): the loop variable may run one grid stride (<= 8192 * 256) past nquads
 bool idx32(int64_t nquads) {
-  static const int on = getenv("CAT_IDX32") ? atoi(getenv("CAT_IDX32")) : 0;
+  constexpr int on = 0;
   return on && nquads < (int64_t)2147483647 - 8192 * 256;
 }
 
@@ -422,6 +444,9 @@ int cat_norm_fwd(const cat_norm_t* g, const float* x, const float* gamma, const 
                                                                    g->mode == CAT_NORM_BATCH ? running_var : nullptr, w + p.scale_off,
                                                                    w + p.shift_off, p.G, p.Pg, g->C, g->cs, p.nb, g->eps, g->momentum,
                                                                    g->mode == CAT_NORM_BATCH ? num_batches_tracked : nullptr);
+  if (g->mode == CAT_NORM_INSTANCE && running_mean && running_var)
+    in_running_kernel<<<cdiv(g->C, 256), 256, 0, s>>>(save_mean, save_rstd, running_mean, running_var, p.G, p.Pg, g->C, g->eps, g->momentum,
+                                                       num_batches_tracked);
   const int64_t nquads = (int64_t)g->N * g->HW * p.nq;
   if (walk_on()) {
     const int nbw = walk_blocks(p);

@@ -31,7 +31,7 @@ from . import optim
 from . import tconv
 
 _ENABLED = os.environ.get('CAT_FUSED_BLOCK', '1') != '0'
-_MERGE_DW_DGRAD = os.environ.get('CAT_FUSED_BLOCK_MERGE_DW_DGRAD', '1') != '0'     # A/B switch
+_MERGE_DW_DGRAD = True      # one N-concatenated launch for the depthwise branches' second-conv input gradients (A/B closed in round 4)
 _BACKWARD_READY = True
 
 
@@ -299,7 +299,7 @@ class _Plan:
             self.key = key
 
 
-_MERGE_PREP = os.environ.get('CAT_MERGE_PREP', '1') != '0'      # A/B switch (round 4)
+_MERGE_PREP = True      # one table-driven preparation launch per generator and step (A/B closed in round 4)
 
 
 def prepare_many(blocks, backward=False):

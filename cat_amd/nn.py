@@ -221,11 +221,12 @@ class _NormMixin:
         act, slope = _act_code(fuse_act)
         if use_batch_stats:
             rm = rv = nbt = None
-            if mode == L.NORM_BATCH and self.training and self.track_running_stats:
+            if self.training and self.track_running_stats:      # BatchNorm2d, and InstanceNorm2d(track_running_stats=True)
                 rm, rv = self.running_mean, self.running_var
                 if self.momentum is None:
                     raise NotImplementedError('cumulative-average BatchNorm (momentum=None)')
-                if count_batches:      # bumped by the finalize kernel: no stock torch kernel in the step
+                if count_batches and mode == L.NORM_BATCH:      # bumped by the finalize kernel: no stock torch kernel in the step (torch's
+                    # _InstanceNorm.forward never touches num_batches_tracked)
                     nbt = self.num_batches_tracked
             return ops.NormActFn.apply(x, self.weight, self.bias, rm, rv, mode, float(self.eps),
                                        float(self.momentum if self.momentum is not None else 0.0), act, slope, nbt)
@@ -245,9 +246,10 @@ class InstanceNorm2d(_NormMixin, nn.InstanceNorm2d):
     def forward(self, x, fuse_act=None, applied=False):
         if applied:      # computed by the producing conv's statistics epilogue; called only so that forward hooks fire
             return x
-        if self.track_running_stats:
-            raise NotImplementedError('InstanceNorm2d(track_running_stats=True) is not used by the distillation scripts')
-        return self._run(x, L.NORM_INSTANCE, True, fuse_act)
+        # track_running_stats=True (models/networks.py:29-64: --norm instance --norm_track_running_stats): instance statistics + running
+        # averages of them in training, the running statistics (a per-channel affine map, like an eval-mode BatchNorm2d) in evaluation
+        use_instance = self.training or not self.track_running_stats
+        return self._run(x, L.NORM_INSTANCE, use_instance, fuse_act)
 
 
 _FUSABLE = (Conv2d, ConvTranspose2d, BatchNorm2d, InstanceNorm2d)     # SynchronizedBatchNorm2d is a BatchNorm2d

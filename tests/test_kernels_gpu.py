@@ -322,6 +322,41 @@ def test_norm_fwd_bwd(dev, mode, c, n, h, w, act):
     assert rel(bg.grad, br.grad) < TOL
 
 
+@pytest.mark.parametrize('affine', [True, False])
+def test_instance_norm_with_running_stats(dev, affine):
+    """nn.InstanceNorm2d(track_running_stats=True) (reference models/networks.py:29-64 with --norm instance --norm_track_running_stats):
+    instance statistics + batch-averaged running statistics (unbiased variance) in training, the running statistics in evaluation --
+    the module against torch's own on the host, two training steps then an eval forward."""
+    from cat_amd import nn as cnn
+    c, n, h, w = 19, 3, 9, 7
+    ref = torch.nn.InstanceNorm2d(c, affine=affine, track_running_stats=True)
+    mod = cnn.InstanceNorm2d(c, affine=affine, track_running_stats=True)
+    if affine:
+        with torch.no_grad():
+            ref.weight.copy_(1.0 + 0.2 * detfill.normal((c,), 31))
+            ref.bias.copy_(0.1 * detfill.normal((c,), 32))
+    mod.load_state_dict(ref.state_dict())
+    mod = mod.to(dev)
+    ref.train(), mod.train()
+    for it in range(2):
+        x = detfill.normal((n, c, h, w), 40 + it) * (1.5 + it) + 0.7
+        xr = x.clone().requires_grad_(True)
+        yr = ref(xr)
+        gy = detfill.normal(tuple(yr.shape), 50 + it)
+        yr.backward(gy)
+        xg = _nhwc(x, dev, True)
+        y = mod(xg)
+        assert rel(y, yr) < TOL
+        y.backward(_nhwc(gy, dev))
+        assert rel(xg.grad, xr.grad) < 5 * TOL
+        assert rel(mod.running_mean, ref.running_mean) < TOL and rel(mod.running_var, ref.running_var) < TOL
+        assert int(mod.num_batches_tracked) == int(ref.num_batches_tracked)      # torch's _InstanceNorm never counts
+    ref.eval(), mod.eval()
+    x = detfill.normal((n, c, h, w), 60)
+    with torch.no_grad():
+        assert rel(mod(_nhwc(x, dev)), ref(x)) < TOL
+
+
 def test_bn_eval_affine(dev):
     from cat_amd import ops
     c = 42

