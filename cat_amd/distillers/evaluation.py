@@ -83,6 +83,8 @@ def attach_fid(model, state_dict, real_stat_path=None, npz=None, dims=2048):
     `state_dict` = the torchvision-keyed FID checkpoint (pt_inception-2015-12-05-6726825d.pth, or a path to it); `real_stat_path` = the
     dataset's precomputed {'mu', 'sigma'} file."""
     from ..metric import InceptionV3
+    if dims != 2048:      # metric.get_fid compares pool3 features with the dataset's 2048-wide {mu, sigma} (metric/__init__.py:11-21)
+        raise ValueError('attach_fid: the FID path uses the 2048-wide pool3 features (dims=%r)' % (dims,))
     if isinstance(state_dict, (str, bytes, os.PathLike)):
         state_dict = torch.load(state_dict, map_location='cpu')
     net = InceptionV3([InceptionV3.BLOCK_INDEX_BY_DIM[dims]])

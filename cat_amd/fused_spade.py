@@ -870,7 +870,8 @@ class _PrepassFn(torch.autograd.Function):
             ctx.layout.append(len(t))
             tensors += t
         ctx.save_for_backward(*tensors)
-        ctx.out_nhwc = [(y.shape[0], y.shape[2], y.shape[3], ops.act_cs(y)) for y in ys]
+        ctx.set_materialize_grads(False)      # an output nobody used reaches backward as None (no dense NCHW zeros, no layout conversion)
+        ctx.out_nhwc = [(y.shape[0], y.shape[2], y.shape[3], ops.act_cs(y), y.shape[1]) for y in ys]
         return tuple(ys)
 
     @staticmethod
@@ -883,7 +884,7 @@ class _PrepassFn(torch.autograd.Function):
             o += cnt
             recs.append(r)
         # an output nobody used arrives as None: its unit still has to step through the lockstep exchanges (every rank does the same)
-        dys = [dy if dy is not None else torch.zeros(shape, device=saved[0].device, dtype=torch.float32).permute(0, 3, 1, 2)
+        dys = [dy if dy is not None else torch.zeros(shape[:4], device=saved[0].device, dtype=torch.float32).permute(0, 3, 1, 2)[:, :shape[4]]
                for dy, shape in zip(dys, ctx.out_nhwc)]
         outs = _drive_many([_backward_g(r, dy) for r, dy in zip(recs, dys)])
         grads = []

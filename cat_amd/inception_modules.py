@@ -358,7 +358,11 @@ class InceptionSPADE(nn.Module):
             return pfn(x, fuse_act=fuse_act)
         from . import fused_spade
         pre = self.__dict__.pop('_cat_gb_pre', None)      # computed by the generator's pre-pass (all SPADE layers in lockstep, N > 1 ranks)
-        if pre is not None and tuple(pre.shape[2:]) == tuple(seg.shape[2:]):
+        if pre is not None:      # (gamma|beta, data pointer, version) of the map it was computed from: a stale entry never meets another input
+            gb_pre, src_ptr, src_ver = pre
+            pre = gb_pre if (src_ptr == segmap.data_ptr() and src_ver == segmap._version and
+                             tuple(gb_pre.shape[2:]) == tuple(seg.shape[2:])) else None
+        if pre is not None:
             gb = pre
         elif fused_spade._UNITS in ('all', 'gb') and fused_spade.applicable(self.res_ops, self.dw_ops, seg, self.training):
             # all first convs / norms / depthwise convs / the 2C-channel branch sum of the gamma|beta net as 5 launches (cat_amd/fused_spade.py)

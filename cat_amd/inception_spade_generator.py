@@ -56,7 +56,7 @@ class InceptionSPADEGenerator(BaseNetwork):
                 if units:
                     import weakref
                     fused_block.prepare_plans(units, weakref.ref(self), False)
-                    self.__dict__['_cat_prep_gen'] = fused_spade.PLAN_GEN
+                self.__dict__['_cat_prep_gen'] = fused_spade.PLAN_GEN      # also without units: the module walk is repeated only when PLAN_GEN moves
         seg = ops.conform(input)
         ret_acts = {}
         self._gb_prepass(seg)
@@ -108,6 +108,10 @@ class InceptionSPADEGenerator(BaseNetwork):
         """Under SynchronizedBatchNorm over several ranks: the gamma|beta nets of ALL SPADE layers read only the segmentation map (reference
         inception_modules.py:746-762), so they run first, in lockstep, with their statistics exchanges merged -- two collectives per pass
         instead of two per layer (fused_spade.prepass); every InceptionSPADE then finds its [gamma | beta] ready.  A no-op on one rank."""
+        # results of an earlier pre-pass that no SPADE layer consumed (a forward that aborted midway) must never meet another input: dropped
+        # on EVERY entry, also when this pass will not run a pre-pass (eval mode, reducer gone)
+        for name, _ in self._block_sizes():
+            getattr(self, name).spade.__dict__.pop('_cat_gb_pre', None)
         if not self.training or ops.bn_sync() is None:
             return
         from . import fused_spade
@@ -115,7 +119,6 @@ class InceptionSPADEGenerator(BaseNetwork):
         for name, size in self._block_sizes():
             blk = getattr(self, name)
             sp = blk.spade
-            sp.__dict__.pop('_cat_gb_pre', None)
             if len(sp.res_ops) + len(sp.dw_ops) == 0 or len(blk.res_ops) + len(blk.dw_ops) == 0:
                 continue      # no gamma|beta net, or a block pruned down to its shortcut (its SPADE layer never runs)
             units.append((sp, sp.res_ops, sp.dw_ops, sp.input_dim, 2 * sp.output_dim, seg_at(seg, size)))
@@ -123,7 +126,7 @@ class InceptionSPADEGenerator(BaseNetwork):
         gbs = fused_spade.prepass(units)
         if gbs is not None:
             for sp, gb in zip(owners, gbs):
-                sp.__dict__['_cat_gb_pre'] = gb
+                sp.__dict__['_cat_gb_pre'] = (gb, seg.data_ptr(), seg._version)      # tagged with the map it was computed from
 
     def remove_spectral_norm(self):
         """Reference inception_spade_generator.py:126-137 (export path)."""

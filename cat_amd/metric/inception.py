@@ -75,6 +75,8 @@ def pool2d(x, k, stride, pad, mode, out=None, c0=0):
     ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
     if out is None:
         out, c0 = ops.empty_act(n, c, ho, wo, x.device), 0
+    elif tuple(out.shape[2:]) != (ho, wo) or out.shape[0] != n or c0 % 4 or c0 + c > out.shape[1]:
+        raise ValueError('pool2d: output slice')      # a wrong slice would overwrite neighbouring channels (the kernel only checks the stride)
     L.call('cat_pool2d_fwd', ops._p(x), ops.act_cs(x), n, h, w, c, k, stride, pad, mode, C.c_void_p(out.data_ptr() + 4 * c0), ops.act_cs(out), ho, wo,
            ops._stream())
     return out
