@@ -37,6 +37,13 @@ class TConv(C.Structure):
                                                                                             ('seg', TSeg * TCONV_MAXSEG)]
 
 
+DWMULTI_MAXQ = 64
+
+
+class DwMulti(C.Structure):
+    _fields_ = [(n, c_i) for n in ('N', 'H', 'W', 'nq', 'xcs', 'ycs', 'reflect', 'act')] + [('slope', c_f), ('ks', c_i * DWMULTI_MAXQ)]
+
+
 KSUM_MAXSEG = 4
 
 
@@ -141,6 +148,7 @@ SIGNATURES = {
     'cat_dwm_bwd': (c_i, [C.POINTER(DwmGeom), c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_p]),
     'cat_prep_run': (c_i, [c_p, c_i, c_i, c_i, c_p]),
     'cat_dwconv2d_fwd': (c_i, [_G, c_p, c_p, c_p, c_p, c_p]),
+    'cat_dwconv2d_multi_fwd': (c_i, [C.POINTER(DwMulti), c_p, c_p, c_p, c_p, c_p]),
     'cat_dwconv2d_dgrad': (c_i, [_G, c_p, c_p, c_p, c_i, c_p]),
     'cat_dwconv2d_wgrad': (c_i, [_G, c_p, c_p, c_p, c_i, c_p, c_p]),
     'cat_dwconv2d_wgrad_ws_bytes': (C.c_size_t, [_G]),

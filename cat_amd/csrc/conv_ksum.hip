@@ -22,7 +22,7 @@
 
 namespace cat_ks {
 
-constexpr int BM = 128, BN = 128, MT = 4, NT = 4, WN = 2;
+constexpr int BM = 128, MT = 4, WN = 2;      // N tile = WN * NT * 16 output channels: NT = 4 (128 wide) or 3 (96 wide: 176 channels = 2 tiles, 8 % padding instead of 31 %)
 constexpr unsigned kOut = 0x80000000u;     // byte offset beyond every buffer: the buffer unit returns zeros and touches no memory
 constexpr int kBadPix = 0x20000000;        // table marker of a source pixel in the zero padding / of a row beyond M
 
@@ -45,7 +45,9 @@ struct Args {
 
 __device__ __forceinline__ int swz32(int r, int q) { return (r * 8 + (q ^ ((r >> 1) & 7))) * 4; }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void ksum_kernel(const Args p) {
+template <int NT>
+__device__ __forceinline__ void ksum_body(const Args& p) {
+  constexpr int BN = WN * NT * 16, BI = BN / 32;      // B rows of the tile, B staging instructions per wave
   extern __shared__ __attribute__((aligned(16))) float smem[];
   typedef __attribute__((address_space(3))) void* lds_t;
   float* sA = smem;
@@ -86,10 +88,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // (row >> 1) & 7 = (4 i + (lane >> 4)) & 7: instructions 0 / 2 fetch quad sqe, instructions 1 / 3 quad sqe ^ 4
   const int slot = lane & 7, lrow = lane >> 3;
   const int sqe = slot ^ ((lrow >> 1) & 3);
-  int srow[4];
-  unsigned voffC[4], voffN[4], voffB[4];     // per staged row: source pixel of the walk's current / next tap (bytes), filter row (bytes)
+  int srow[4], srowB[BI], sqB[BI];
+  unsigned voffC[4], voffN[4], voffB[BI];    // per staged row: source pixel of the walk's current / next tap (bytes), filter row (bytes)
 #pragma unroll
   for (int i = 0; i < 4; ++i) srow[i] = (wave * 4 + i) * 8 + lrow;
+#pragma unroll
+  for (int i = 0; i < BI; ++i) {             // the B tile has BN = 32 BI rows: wave w, instruction i -> rows (w * BI + i) * 8 + (lane >> 3)
+    srowB[i] = (wave * BI + i) * 8 + lrow;
+    sqB[i] = slot ^ ((srowB[i] >> 1) & 7);
+  }
 
   // walk state of the NEXT chunk to fetch (wave-uniform).  K of a segment = the flattened sequence of (tap, channel quad) pairs; a chunk is
   // the next <= 8 of them (q >= 8: it may straddle ONE tap boundary, each lane picks the tap its quad belongs to) or, for q < 8, one tap
@@ -129,8 +136,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     wxcs4 = (unsigned)sg.xcs * 4u;
     const unsigned wrow4 = (unsigned)sg.wrow * 4u;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int co = n0 + srow[i];
+    for (int i = 0; i < BI; ++i) {
+      const int co = n0 + srowB[i];
       const unsigned v = (unsigned)co * wrow4;
       voffB[i] = co < p.Cout ? v : kOut;
     }
@@ -147,26 +154,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int nq = wflat ? min(8, left) : wq;
     if (!(var & 4)) {
       float* dA = sA + buf * BM * 32 + wave * 4 * 256;
-      float* dB = sB + buf * BN * 32 + wave * 4 * 256;
+      float* dB = sB + buf * BN * 32 + wave * BI * 256;
       const unsigned tapB = (unsigned)wtap * wwcs4;
 #pragma unroll
       for (int par = 0; par < 2; ++par) {
-        const int sq = sqe ^ (par * 4);                       // this lane's quad slot of the chunk in instructions par, par + 2
+        const int sq = sqe ^ (par * 4);                       // this lane's quad slot of the chunk in A instructions par, par + 2
         const int t = wq0 + sq;
         const bool nxt = t >= wq;                            // flat chunks only (q < 8: nq = q <= t is masked below)
         const unsigned qoff = (unsigned)(nxt ? t - wq : t) * 16u;
         const bool valid = sq < nq;
-        const unsigned boff = (nxt ? tapB + wwcs4 : tapB) + qoff;
 #pragma unroll
         for (int i = par; i < 4; i += 2) {
           const unsigned va = (nxt ? voffN[i] : voffC[i]) + qoff;
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_t)(dA + i * 256), 16, valid ? va : kOut, 0, 0, 0);
         }
+      }
 #pragma unroll
-        for (int i = par; i < 4; i += 2) {
-          const unsigned vb = voffB[i] + boff;
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_t)(dB + i * 256), 16, valid ? vb : kOut, 0, 0, 0);
-        }
+      for (int i = 0; i < BI; ++i) {
+        const int t = wq0 + sqB[i];
+        const bool nxt = t >= wq;
+        const unsigned boff = (nxt ? tapB + wwcs4 : tapB) + (unsigned)(nxt ? t - wq : t) * 16u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_t)(dB + i * 256), 16, sqB[i] < nq ? voffB[i] + boff : kOut, 0, 0, 0);
       }
     }
     wq0 += nq;
@@ -279,6 +287,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
 }
 
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void ksum_kernel4(const Args p) { ksum_body<4>(p); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void ksum_kernel3(const Args p) { ksum_body<3>(p); }
+
 }  // namespace cat_ks
 
 extern "C" {
@@ -320,11 +331,15 @@ int cat_conv2d_ksum_fwd(const cat_ksum_t* g, const float* bias, const float* res
   const int64_t M = (int64_t)g->N * g->H * g->W;
   CAT_REQUIRE(M < (int64_t)cat_ks::kBadPix, "conv ksum: too many pixels");
   a.M = (int)M;
-  const int64_t grid = (int64_t)cat::cdiv(M, cat_ks::BM) * cat::cdiv(g->Cout, cat_ks::BN);
+  // 96-wide N tiles where they pad less than 128-wide ones (176 output channels: 192 instead of 256 columns)
+  const bool n96 = cat::cdiv(g->Cout, 96) * 96 < cat::cdiv(g->Cout, 128) * 128;
+  const int bn = n96 ? 96 : 128;
+  const int64_t grid = (int64_t)cat::cdiv(M, cat_ks::BM) * cat::cdiv(g->Cout, bn);
   CAT_REQUIRE(grid < (int64_t)2147483647, "conv ksum: grid too large");
-  const size_t lds = (size_t)2 * (cat_ks::BM + cat_ks::BN) * 32 * sizeof(float) + (size_t)2 * cat_ks::BM * 8 * sizeof(int);
-  static cat::LdsOptIn optin;
-  cat::lds_optin(optin, (const void*)cat_ks::ksum_kernel, (int)lds);
+  const size_t lds = (size_t)2 * (cat_ks::BM + bn) * 32 * sizeof(float) + (size_t)2 * cat_ks::BM * 8 * sizeof(int);
+  static cat::LdsOptIn optin3, optin4;
+  if (n96) cat::lds_optin(optin3, (const void*)cat_ks::ksum_kernel3, (int)lds);
+  else cat::lds_optin(optin4, (const void*)cat_ks::ksum_kernel4, (int)lds);
   static const int var_env = [] {
     const int v = (cat::kDiag && getenv("CAT_KSUM_VAR")) ? atoi(getenv("CAT_KSUM_VAR")) : 0;
     if (v) fprintf(stderr, "libcat_hip: CAT_KSUM_VAR=%d -- ksum results are INTENTIONALLY WRONG (timing diagnostics only)\n", v);
@@ -332,7 +347,8 @@ int cat_conv2d_ksum_fwd(const cat_ksum_t* g, const float* bias, const float* res
   }();
   a.var = var_env;
   cat::ProfScope prof("conv_ksum", 2.0 * (double)M * g->Cout * kflops, 0.0, stream);
-  cat_ks::ksum_kernel<<<(int)grid, 256, lds, (hipStream_t)stream>>>(a);
+  if (n96) cat_ks::ksum_kernel3<<<(int)grid, 256, lds, (hipStream_t)stream>>>(a);
+  else cat_ks::ksum_kernel4<<<(int)grid, 256, lds, (hipStream_t)stream>>>(a);
   return cat::check_launch("conv2d_ksum_fwd");
 }
 

@@ -66,6 +66,87 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs p) {
   }
 }
 
+// Several depthwise convs of DIFFERENT kernel sizes over adjacent channel slices of one buffer as ONE launch (round 6: the frozen teacher's
+// block, cat_amd/frozen.py -- its 1 x 1 / 3 x 3 / 5 x 5 depthwise convs with eval-mode BatchNorm folded in, plus the plain copy of the k = 1
+// residual branch's hidden slice, were four launches of 10 - 32 us over the same 176-channel buffers).  Per channel quad a kernel size
+// k in {1, 3, 5}; the filters sit in a 5 x 5 frame [25][cs] (k < 5: centred, the rest zero -- only the k x k window is read), a quad that is
+// merely copied carries k = 1, centre weight 1, bias 0.  Lane = (pixel, quad): a pixel's quads are consecutive lanes (one coalesced row).
+struct DwMultiArgs {
+  const float* x; const float* w25; const float* bias; float* y;
+  int N, H, W, nq, xcs, ycs, reflect, act;
+  float slope;
+  // runs of consecutive quads with the same kernel size: threads are dealt out run by run ([run][pixel][quad of the run]), so a wave has ONE
+  // kernel size (no divergence, fully unrolled tap loops: all k * k loads of a thread in flight at once)
+  int nrun;
+  int run_q0[CAT_DWMULTI_MAXRUN], run_nq[CAT_DWMULTI_MAXRUN], run_k[CAT_DWMULTI_MAXRUN];
+  long long run_base[CAT_DWMULTI_MAXRUN + 1];      // first thread index of the run; [nrun] = total
+};
+
+template <int K>
+__device__ __forceinline__ f4 dw_multi_taps(const DwMultiArgs& p, const float* sw, const float* xn, int oy, int ox, int c, int cs, f4 acc) {
+  constexpr int R = K / 2, O = 2 - R;
+  int64_t offy[K];
+  int offx[K];
+  bool vy[K], vx[K];
+#pragma unroll
+  for (int t = 0; t < K; ++t) {
+    int iy = oy - R + t, ix = ox - R + t;
+    vy[t] = p.reflect || (unsigned)iy < (unsigned)p.H;
+    vx[t] = p.reflect || (unsigned)ix < (unsigned)p.W;
+    iy = p.reflect ? cat::reflect_idx(iy, p.H) : (vy[t] ? iy : 0);
+    ix = p.reflect ? cat::reflect_idx(ix, p.W) : (vx[t] ? ix : 0);
+    offy[t] = (int64_t)iy * p.W * p.xcs;
+    offx[t] = ix * p.xcs;
+  }
+  f4 xv[K][K];
+#pragma unroll
+  for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < K; ++kx) xv[ky][kx] = *reinterpret_cast<const f4*>(xn + offy[ky] + offx[kx]);
+#pragma unroll
+  for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < K; ++kx) {
+      const f4 wv = *reinterpret_cast<const f4*>(sw + ((O + ky) * 5 + O + kx) * cs + c);
+      const float mk = (vy[ky] && vx[kx]) ? 1.f : 0.f;      // out-of-plane taps read pixel (0, 0): masked, never skipped
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] = fmaf(xv[ky][kx][e] * mk, wv[e], acc[e]);
+    }
+  return acc;
+}
+
+__global__ __launch_bounds__(256) void dw_multi_fwd_kernel(DwMultiArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float sw[];      // [25][cs] frame, then [cs] bias
+  const int cs = p.nq * 4;
+  for (int i = threadIdx.x; i < 25 * p.nq; i += 256) *reinterpret_cast<f4*>(sw + i * 4) = *reinterpret_cast<const f4*>(p.w25 + i * 4);
+  for (int i = threadIdx.x; i < p.nq; i += 256)
+    *reinterpret_cast<f4*>(sw + 25 * cs + i * 4) = p.bias ? *reinterpret_cast<const f4*>(p.bias + i * 4) : f4{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+  const int64_t total = p.run_base[p.nrun];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    int r = 0;
+    while (r + 1 < p.nrun && i >= p.run_base[r + 1]) ++r;
+    const int64_t j = i - p.run_base[r];
+    const int rq = p.run_nq[r], k = p.run_k[r];
+    const int cq = p.run_q0[r] + (int)(j % rq);
+    int64_t pix = j / rq;
+    const int64_t opix = pix;
+    const int ox = (int)(pix % p.W);
+    pix /= p.W;
+    const int oy = (int)(pix % p.H);
+    const int n = (int)(pix / p.H);
+    const int c = cq * 4;
+    f4 acc = *reinterpret_cast<const f4*>(sw + 25 * cs + c);
+    const float* xn = p.x + (int64_t)n * p.H * p.W * p.xcs + c;
+    if (k == 1) acc = dw_multi_taps<1>(p, sw, xn, oy, ox, c, cs, acc);
+    else if (k == 3) acc = dw_multi_taps<3>(p, sw, xn, oy, ox, c, cs, acc);
+    else acc = dw_multi_taps<5>(p, sw, xn, oy, ox, c, cs, acc);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] = cat::apply_act(acc[e], p.act, p.slope);
+    *reinterpret_cast<f4*>(p.y + opix * p.ycs + c) = acc;
+  }
+}
+
 // dxp[n,py,px,c] = sum_k dy[n, py+pe-ky, px+pe-kx, c] * w[c,ky,kx]; (Hin,Win,pe) = (H+2p,W+2p,0) for reflect, (H,W,p) for zero pad.
 __global__ __launch_bounds__(256) void dw_dgrad_kernel(DwArgs p, int Hin, int Win, int pe, int dxcs) {
   extern __shared__ __attribute__((aligned(16))) float sw[];
@@ -206,6 +287,37 @@ int cat_dwconv2d_fwd(const cat_conv_t* g, const float* x, const float* w, const 
   cat::ProfScope prof("dwconv_fwd", 2.0 * g->N * g->Ho * g->Wo * g->Cin * g->kh * g->kw, 2 * 4.0 * (double)g->N * g->Ho * g->Wo * own, stream);
   dw_fwd_kernel<<<ew_grid((int64_t)g->N * g->Ho * g->Wo * a.cq), 256, (size_t)g->kh * g->kw * own * sizeof(float), (hipStream_t)stream>>>(a);
   return cat::check_launch("dwconv2d_fwd");
+}
+
+int cat_dwconv2d_multi_fwd(const cat_dwmulti_t* g, const float* x, const float* w25, const float* bias, float* y, cat_stream_t stream) {
+  CAT_REQUIRE(g->N > 0 && g->H > 0 && g->W > 0 && g->nq > 0 && g->nq <= CAT_DWMULTI_MAXQ, "dwconv multi: bad geometry (nq=%d)", g->nq);
+  CAT_REQUIRE((g->xcs & 3) == 0 && (g->ycs & 3) == 0 && g->xcs >= 4 * g->nq && g->ycs >= 4 * g->nq, "dwconv multi: pixel strides");
+  DwMultiArgs a{};
+  a.x = x; a.w25 = w25; a.bias = bias; a.y = y;
+  a.N = g->N; a.H = g->H; a.W = g->W; a.nq = g->nq; a.xcs = g->xcs; a.ycs = g->ycs; a.reflect = g->reflect; a.act = g->act; a.slope = g->slope;
+  double taps = 0.0;
+  const int64_t npix = (int64_t)g->N * g->H * g->W;
+  a.nrun = 0;
+  a.run_base[0] = 0;
+  for (int q = 0; q < g->nq; ++q) {
+    const int k = g->ks[q];
+    CAT_REQUIRE(k == 1 || k == 3 || k == 5, "dwconv multi: kernel size %d of quad %d", k, q);
+    CAT_REQUIRE(!g->reflect || (k / 2 < g->H && k / 2 < g->W), "dwconv multi: reflect padding wider than the plane");
+    taps += 4.0 * k * k;
+    if (a.nrun == 0 || a.run_k[a.nrun - 1] != k) {
+      CAT_REQUIRE(a.nrun < CAT_DWMULTI_MAXRUN, "dwconv multi: more than %d runs of equal kernel size", CAT_DWMULTI_MAXRUN);
+      a.run_q0[a.nrun] = q;
+      a.run_nq[a.nrun] = 0;
+      a.run_k[a.nrun] = k;
+      ++a.nrun;
+    }
+    ++a.run_nq[a.nrun - 1];
+  }
+  for (int r = 0; r < a.nrun; ++r) a.run_base[r + 1] = a.run_base[r] + npix * a.run_nq[r];
+  const double pix = (double)npix;
+  cat::ProfScope prof("dwconv_fwd", 2.0 * pix * taps, 2 * 4.0 * pix * 4 * g->nq, stream);
+  dw_multi_fwd_kernel<<<ew_grid(npix * g->nq), 256, (size_t)26 * 4 * g->nq * sizeof(float), (hipStream_t)stream>>>(a);
+  return cat::check_launch("dwconv2d_multi_fwd");
 }
 
 int cat_dwconv2d_dgrad(const cat_conv_t* g, const float* dy, const float* w, float* dx, int dxcs, cat_stream_t stream) {

@@ -120,7 +120,27 @@ def _plan(block):
             b_f += last.bias.detach() * s_pw
         wides.append(dict(op=op, w2=w2, k=last.kernel_size[0]))
     act, slope = cnn._act_code(act_mod)
-    plan = dict(key=key, tail_pack=None, tail_offs=None, hc=hc, w_a=w_a, b_a=b_a.contiguous(), w_f=w_f, b_f=b_f.contiguous(), dws=dws, wides=wides, act=act, slope=slope,
+    # all depthwise convs (+ the copy of the k = 1 residual branch's hidden slice) as ONE launch (cat_dwconv2d_multi_fwd): filters in a 5 x 5
+    # frame [25][hc], folded bias, kernel size per channel quad.  The copy is k = 1 with centre weight 1: act(h) = h for an activation
+    # that is idempotent (ReLU; LeakyReLU is not: slope^2 on negative values) -- anything else keeps the separate launches
+    dwm = None
+    if dws and hc // 4 <= L.DWMULTI_MAXQ and all(d['k'] in (1, 3, 5) for d in dws) and act in (L.ACT_RELU, L.ACT_NONE):
+        frame = torch.zeros((25, hc), device=dev)
+        fbias = torch.zeros(hc, device=dev)
+        ks = [1] * (hc // 4)
+        for (kind, _), (o, m, sz) in zip(slots, offs):
+            if kind == 'res':
+                frame[12, o:o + m] = 1.0
+        for d in dws:
+            k, o2 = d['k'], 2 - d['k'] // 2
+            for ky in range(k):
+                for kx in range(k):
+                    frame[(o2 + ky) * 5 + o2 + kx, d['off']:d['off'] + d['m']] = d['w'][:, 0, ky, kx]
+            fbias[d['off']:d['off'] + d['m']] = d['b']
+            for q in range(d['off'] // 4, (d['off'] + d['sz']) // 4):
+                ks[q] = k
+        dwm = dict(frame=frame.contiguous(), bias=fbias.contiguous(), ks=ks)
+    plan = dict(key=key, tail_pack=None, tail_offs=None, hc=hc, dwm=dwm, w_a=w_a, b_a=b_a.contiguous(), w_f=w_f, b_f=b_f.contiguous(), dws=dws, wides=wides, act=act, slope=slope,
                 pad_mode=pad_mode, copies=[(o, sz) for (kind, _), (o, m, sz) in zip(slots, offs) if kind == 'res'])
     block._cat_frozen = plan
     return plan
@@ -136,8 +156,23 @@ def block_forward(block, x):
     def concat_chain(xi):
         # A: every first-level 1x1 conv (+ folded BN + activation) as one GEMM
         stc = ops._stream()
-        hbuf = ops.Conv2dFn.apply(xi, p['w_a'], p['b_a'], 1, 0, L.PAD_ZERO, p['act'], p['slope'])
+        from . import ksum
+        aseg = [ksum.Segment(xi, p['w_a'], False)]
+        if ksum.applicable(aseg, n, h, w, hc):      # 176 wide: two 96-column tiles of the DMA-staged GEMM (8 % padding; 128-wide tiles: 31 %)
+            hbuf = ksum.run(aseg, p['b_a'], ops.empty_act(n, hc, h, w, xi.device), act=p['act'], slope=p['slope'])
+        else:
+            hbuf = ops.Conv2dFn.apply(xi, p['w_a'], p['b_a'], 1, 0, L.PAD_ZERO, p['act'], p['slope'])
         h2 = ops.empty_act(n, hc, h, w, xi.device)
+        if p['dwm'] is not None:
+            gm = L.DwMulti()
+            gm.N, gm.H, gm.W, gm.nq, gm.xcs, gm.ycs = n, h, w, hc // 4, hc, hc
+            gm.reflect, gm.act, gm.slope = int(p['pad_mode'] == L.PAD_REFLECT), p['act'], p['slope']
+            for q, k in enumerate(p['dwm']['ks']):
+                gm.ks[q] = k
+            L.call('cat_dwconv2d_multi_fwd', C.byref(gm), ops._p(hbuf), ops._p(p['dwm']['frame']), ops._p(p['dwm']['bias']), ops._p(h2), stc)
+            if fused_tail:
+                return h2
+            return ops.Conv2dFn.apply(h2, p['w_f'], p['b_f'], 1, 0, L.PAD_ZERO, L.ACT_NONE, 0.0)
         for o, sz in p['copies']:       # k = 1 res branch: its hidden activation already is the last conv's input
             L.call('cat_slice_channels', ops._p(hbuf), hc, o, sz, C.c_void_p(h2.data_ptr() + 4 * o), hc, m_pix, stc)
         for d in p['dws']:              # depthwise k x k (+ folded BN + activation) on a channel slice of the concatenated buffers

@@ -84,6 +84,23 @@ int cat_conv2d_dgrad_ws(const cat_conv_t* g, const float* dy, const float* w, co
  * point at the slice's first channel, xcs / ycs are the buffers' pixel strides, ycw = channels incl. padding the slice owns). */
 int cat_dwconv2d_fwd(const cat_conv_t* g, const float* x, const float* w, const float* bias, float* y,
                      cat_stream_t stream);
+/* Several depthwise convs of different kernel sizes over ADJACENT channel slices of one buffer as one launch (csrc/dwconv.hip): per channel
+ * quad a kernel size in {1, 3, 5}, filters in a 5 x 5 frame w25[25][4*nq] (centred, zero outside the k x k window), bias[4*nq] (or NULL),
+ * y = act(conv + bias).  The frozen (eval-mode, BatchNorm-folded) teacher's InvertedResidualChannels block: its three groups=midp
+ * ConvBNReLU convs (inception_modules.py:166-173) and the copy of the k = 1 residual branch's hidden slice (k = 1, centre weight 1) --
+ * torch: 3 x F.conv2d(groups=C) + 3 x F.batch_norm + 3 x relu + a slice copy. */
+#define CAT_DWMULTI_MAXQ 64
+#define CAT_DWMULTI_MAXRUN 8   /* runs of consecutive quads with one kernel size */
+typedef struct {
+  int N, H, W;
+  int nq;                  /* channel quads */
+  int xcs, ycs;            /* pixel strides of x / y (x and y point at the first channel of the slice range) */
+  int reflect;             /* source pixels outside the plane: 1 = mirrored, 0 = zero */
+  int act;                 /* epilogue activation */
+  float slope;
+  int ks[CAT_DWMULTI_MAXQ];
+} cat_dwmulti_t;
+int cat_dwconv2d_multi_fwd(const cat_dwmulti_t* g, const float* x, const float* w25, const float* bias, float* y, cat_stream_t stream);
 int cat_dwconv2d_dgrad(const cat_conv_t* g, const float* dy, const float* w, float* dx, int dxcs,
                        cat_stream_t stream);
 int cat_dwconv2d_wgrad(const cat_conv_t* g, const float* x, const float* dy, float* dw, int accumulate, void* ws,

@@ -322,6 +322,51 @@ def test_norm_fwd_bwd(dev, mode, c, n, h, w, act):
     assert rel(bg.grad, br.grad) < TOL
 
 
+@pytest.mark.parametrize('reflect', [True, False])
+def test_dwconv_multi_fwd(dev, reflect):
+    """cat_dwconv2d_multi_fwd: depthwise convs of kernel sizes 1 / 3 / 5 (+ a copied slice) over adjacent channel slices of one buffer as ONE
+    launch, against F.conv2d(groups=C) per slice on the host -- the frozen teacher's block in small (42-channel slices in 44-channel slots)."""
+    import ctypes as C
+    from cat_amd import ops, _lib as L
+    n, h, w, m = 2, 11, 9, 42
+    sz = 44
+    hc = 4 * sz
+    x = F.relu(detfill.normal((n, hc, h, w), 71))
+    for s_ in range(4):
+        x[:, s_ * sz + m:(s_ + 1) * sz] = 0.0          # padding channels of a slot hold zeros
+    frame = torch.zeros(25, hc)
+    bias = torch.zeros(hc)
+    want = torch.zeros(n, hc, h, w)
+    want[:, :m] = x[:, :m]                             # slot 0: the copied slice (k = 1, centre weight 1)
+    frame[12, :m] = 1.0
+    ks = [1] * (hc // 4)
+    for s_, k in ((1, 1), (2, 3), (3, 5)):
+        wt = detfill.normal((m, 1, k, k), 80 + k) / k
+        b = 0.1 * detfill.normal((m,), 90 + k)
+        xs = x[:, s_ * sz:s_ * sz + m]
+        p = k // 2
+        xp = F.pad(xs, (p, p, p, p), mode='reflect') if (reflect and p) else xs
+        want[:, s_ * sz:s_ * sz + m] = F.relu(F.conv2d(xp, wt, b, 1, 0 if (reflect and p) else p, 1, m))
+        o2 = 2 - p
+        for ky in range(k):
+            for kx in range(k):
+                frame[(o2 + ky) * 5 + o2 + kx, s_ * sz:s_ * sz + m] = wt[:, 0, ky, kx]
+        bias[s_ * sz:s_ * sz + m] = b
+        for q in range(s_ * sz // 4, (s_ + 1) * sz // 4):
+            ks[q] = k
+    xg = _nhwc(x, dev)
+    y = ops.empty_act(n, hc, h, w, dev)
+    g = L.DwMulti()
+    g.N, g.H, g.W, g.nq, g.xcs, g.ycs, g.reflect, g.act, g.slope = n, h, w, hc // 4, hc, hc, int(reflect), L.ACT_RELU, 0.0
+    for q, k in enumerate(ks):
+        g.ks[q] = k
+    frame_d, bias_d = frame.to(dev).contiguous(), bias.to(dev)      # held until the launch has run (a temporary's block would be re-used)
+    L.call('cat_dwconv2d_multi_fwd', C.byref(g), ops._p(xg), ops._p(frame_d), ops._p(bias_d), ops._p(y), ops._stream())
+    torch.cuda.synchronize()
+    assert rel(y, want) < TOL
+    assert float(y.cpu()[:, m:sz].abs().max()) == 0.0      # padding channels stay exact zeros
+
+
 @pytest.mark.parametrize('affine', [True, False])
 def test_instance_norm_with_running_stats(dev, affine):
     """nn.InstanceNorm2d(track_running_stats=True) (reference models/networks.py:29-64 with --norm instance --norm_track_running_stats):

@@ -41,6 +41,9 @@ CASES = [
     ([(8, 5), (20, 1), (4, 3), (36, 3)], 77, False, 2, 10, 10, True, False, 0),   # 1..3-quad remainder steps only / 2 full sets + 1
     ([(64, 3), (12, 1)], 128, True, 1, 8, 64, False, True, 0),                # 2 full sets per chunk (16 quads = 8 + 8), 3-quad chunk
     ([(256, 1)], 64, False, 2, 7, 9, True, True, 1),
+    ([(256, 1)], 176, False, 2, 16, 16, True, False, 1),                      # the teacher's merged first 1 x 1 GEMM: two 96-wide N tiles
+    ([(44, 3), (20, 1)], 150, True, 1, 12, 12, True, True, 0),                # 96-wide tiles with a ragged second tile (54 of 96 columns)
+    ([(32, 5)], 96, False, 1, 9, 9, False, False, 0),                         # exactly one 96-wide tile
 ]
 
 
