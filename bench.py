@@ -515,8 +515,8 @@ def student_forward_rate(model, batch, spade, graph=True):
             'batch': int(x.shape[0])}
 
 
-PROFILE_TAG = 'r05'
-PMC_FILE = f'profiles/{PROFILE_TAG}_pmc_hbm_patchgan_fwd.json'
+PROFILE_TAG = 'r06'
+PMC_FILE = f'profiles/{PROFILE_TAG}_pmc_hbm.json'
 STATS_FILE = f'profiles/{PROFILE_TAG}_kernel_stats_c2.txt'
 META_FILE = f'profiles/{PROFILE_TAG}_meta.json'          # {"commit": ..., "date": ...}: the tree the committed profiles were taken from
 
@@ -532,7 +532,7 @@ def _profile_commit():
 
 def _profiles_stale():
     """True if the committed profiles (kernel stats / PMC tables this line quotes) were taken from OTHER kernel sources than the ones running
-    now (profiles/<tag>_meta.json records the csrc fingerprint of the tree tools/profile_round.sh ran on); None if the meta file has none."""
+    now (profiles/<tag>_meta.json records the csrc fingerprint of the tree tools/profile_r6.sh ran on); None if the meta file has none."""
     meta = _profile_meta()
     fp = meta.get('csrc_sha')
     return None if fp is None else fp != csrc_fingerprint(tuple(meta.get('added_after', ())))
@@ -540,8 +540,8 @@ def _profiles_stale():
 
 def pmc_traffic(family):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (PMC_FILE: FETCH_SIZE and WRITE_SIZE in separate
-    passes, FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md §HBM; round 5: taken over tools/debug/patchgan_fwd_trace.py, the
-    PatchGAN forward of this workload, because the whole-step passes no longer fit the GPU budget of the round).  PMC collection cannot run
+    passes, FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md §HBM; round 6: whole-step passes restricted to the library's conv /
+    norm / depthwise kernels by --kernel-include-regex, tools/profile_r6.sh).  PMC collection cannot run
     inside the timed process, hence the lookup; None if absent."""
     path = os.path.join(ROOT, PMC_FILE)
     if not os.path.exists(path):
@@ -617,9 +617,10 @@ def kernel_roofline(model, step, args):
     gflop_launch = d['gflop_per_step'] / max(d['launches_per_step'], 1)
     return {'bound': 'mfma', 'kernel': dom, 'achieved': round(achieved, 3), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
             'frac': round(achieved / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': pmc_traffic(dom) if headline else None,
-            'traffic_source': PMC_FILE + ' (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the PatchGAN forward of this workload: the three '
-                              'wide PatchGAN layers = 9 of the 20 launches of the family per step; not a same-run measurement.  Whole-step family average of '
-                              'round 4, identical tile: 421 MB per launch, profiles/r04_pmc_hbm.json)',
+            'traffic_source': PMC_FILE + ' (tools/profile_r6.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, --kernel-trace only, over 2 serial '
+                              'steps of this command, counters collected for the conv / norm / depthwise kernels through --kernel-include-regex; per-launch '
+                              'average over ALL launches of the family in the step, FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md; not a '
+                              'same-run measurement)',
             'avg_launch_us': round(avg_us, 3),
             # the same fraction from the committed rocprofv3 --kernel-trace --stats summary (its average launch duration of this kernel):
             # HIP events see the kernel alone, rocprof's span includes dispatch overhead -- the two bracket the truth (~3 % apart)
