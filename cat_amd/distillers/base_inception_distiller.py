@@ -211,6 +211,82 @@ class BaseInceptionDistiller:
         torch.autograd.backward([self.loss_D_fake, self.loss_D_real], [self.seed(0.5), self.seed(0.5)])
         ops.sync_side_streams()
 
+    # -- backward_D in gradient-ready STAGES (data-parallel schedule, SURVEY 8e legal overlap 2) ---------------------------------------
+    def d_stage_plan(self):
+        """How backward_D can be cut so that the discriminator's gradient bucket leaves in slices while the rest of the pass still runs:
+        -> (segments, slices) or None.  `segments`: the PatchGAN's layer list split in front of its two widest convolutions (pix2pix D:
+        [conv1 .. bn2 act | conv3 bn3 act | conv4 bn4 act conv5]); `slices`: per segment the (lo, hi) float range its parameters occupy in
+        optimizer_D's flat gradient buffer.  The last segment (the 512 -> 1024 conv: 8.4 M of 11 M parameters) is differentiated first."""
+        cached = self.__dict__.get('_d_stage_plan')
+        if cached is not None and cached[0] is self.netD:
+            return cached[1]
+        plan = None
+        from ..discriminators import NLayerDiscriminator
+        from .. import nn as cnn
+        mods = getattr(self.netD, 'model', None)
+        flat = self.optimizer_D._ensure_flat() if hasattr(self.optimizer_D, '_ensure_flat') else None
+        if isinstance(self.netD, NLayerDiscriminator) and isinstance(mods, cnn.FusedSequential) and flat is not None and len(flat) == 1 and \
+                flat[0] is not None and not any(m._forward_hooks or m._forward_pre_hooks for m in mods):
+            convs = [i for i, m in enumerate(mods) if isinstance(m, cnn.Conv2d)]
+            if len(convs) >= 4:
+                order = sorted(convs[1:], key=lambda i: -mods[i].weight.numel())[:2]      # the two widest convs that are not the first layer
+                cuts = sorted(order)
+                segments = [mods[:cuts[0]], mods[cuts[0]:cuts[1]], mods[cuts[1]:]]
+                f = flat[0]
+                where = {id(q): (o, f['offs'][j + 1] if j + 1 < len(f['offs']) else f['n']) for j, (q, o) in enumerate(zip(f['params'], f['offs']))}
+                slices, ok, pos = [], True, 0
+                for seg in segments:
+                    ps = list(seg.parameters())
+                    lo, hi = where[id(ps[0])][0], where[id(ps[-1])][1]
+                    ok = ok and lo == pos and all(where[id(a)][1] == where[id(b)][0] for a, b in zip(ps, ps[1:]))
+                    slices.append((lo, hi))
+                    pos = hi
+                dparams = list(self.netD.parameters())
+                if ok and pos == f['n'] and len(dparams) == len(f['params']) and all(a is b for a, b in zip(dparams, f['params'])):
+                    plan = (segments, slices)
+        self.__dict__['_d_stage_plan'] = (self.netD, plan)
+        return plan
+
+    def backward_D_stages(self):
+        """backward_D as three callables, same kernels in the same per-parameter order (real graph, then fake graph) -- bit-identical
+        gradients: stage 0 = both discriminator forwards, the losses and the backward pass of the LAST segment; stage 1 / 2 = the
+        middle / first segment.  After stage k the gradient slice `slices[2 - k]` of optimizer_D's bucket is final."""
+        segments, slices = self.d_stage_plan()
+        st = {}
+
+        def stage0():
+            with torch.no_grad():
+                if self.opt.dataset_mode == 'aligned':
+                    fake = ops.Concat2Fn.apply(self.real_A, self.Sfake_B.detach())
+                    real = ops.Concat2Fn.apply(self.real_A, self.real_B)
+                else:
+                    fake = self.Sfake_B.detach()
+                    real = self.real_B
+            cf = [segments[0](fake)]
+            cf.append(segments[1](cf[0]))
+            pred_fake = segments[2](cf[1])
+            self.loss_D_fake = self.criterionGAN(pred_fake, False, for_discriminator=True)
+            cr = [segments[0](real)]
+            cr.append(segments[1](cr[0]))
+            pred_real = segments[2](cr[1])
+            self.loss_D_real = self.criterionGAN(pred_real, True, for_discriminator=True)
+            self.loss_D = LossValue([(0.5, self.loss_D_fake), (0.5, self.loss_D_real)])
+            st['cuts'] = (cf, cr)
+            st['g'] = torch.autograd.grad([self.loss_D_fake, self.loss_D_real], [cf[1], cr[1]], [self.seed(0.5), self.seed(0.5)])
+            ops.sync_side_streams()
+
+        def stage1():
+            cf, cr = st['cuts']
+            st['g'] = torch.autograd.grad([cf[1], cr[1]], [cf[0], cr[0]], list(st['g']))
+            ops.sync_side_streams()
+
+        def stage2():
+            cf, cr = st['cuts']
+            torch.autograd.backward([cf[0], cr[0]], list(st['g']))
+            st.clear()
+            ops.sync_side_streams()
+        return [stage0, stage1, stage2], [slices[2], slices[1], slices[0]]
+
     # -- bookkeeping shared with models/base_model.py:146-232 -------------------------------------------------
     def set_requires_grad(self, nets, requires_grad=False):
         if not isinstance(nets, list):

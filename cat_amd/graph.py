@@ -100,6 +100,8 @@ class GraphedDPStep:
         side : g_T   (frozen-teacher forward of this batch -- overlaps the wait for the previous step's student all-reduce)
         main : [wait G bucket of the previous step -> Adam G (one eager launch)] -> g_A (student forward, backward_D)
                -> RCCL all-reduce of the D bucket -> join side -> g_B (Adam D, backward_G) -> async all-reduce of the G bucket
+        g_A is THREE graphs when the discriminator can be cut (InceptionDistiller._dp_first_stages): after each one the gradient slice that
+        became final (first the 512 -> 1024 layer's 8.4 M of 11 M parameters) is all-reduced while the next graph runs.
 
     Without a reducer (one GPU, `model.dp is None`) the same four graphs run with no collective in between and Adam G at the end of g_B:
     the teacher then simply overlaps the student forward + discriminator step.  g_T has its own memory pool (it runs concurrently with
@@ -135,14 +137,23 @@ class GraphedDPStep:
             parallel.settle_collectives()      # the RCCL watchdog must not poll a warm-up collective's event inside a capture
         side = model._side_stream
         kw = dict(capture_error_mode='thread_local')      # RCCL's watchdog thread may query events while this thread captures
-        self.g_in, self.g_T, self.g_A, self.g_B = (torch.cuda.CUDAGraph() for _ in range(4))
+        self.g_in, self.g_T, self.g_B = (torch.cuda.CUDAGraph() for _ in range(3))
         with torch.cuda.graph(self.g_in, **kw):
             model.set_input(self.static)
         with torch.cuda.graph(self.g_T, stream=side, **kw):
             model._dp_teacher()
-        with torch.cuda.graph(self.g_A, **kw):
-            model._dp_first()
-        with torch.cuda.graph(self.g_B, pool=self.g_A.pool(), **kw):
+        # student forward + backward_D: one graph, or -- with a reducer and a discriminator that can be cut -- one graph per gradient-ready
+        # stage, so that each slice of the D bucket is all-reduced while the next stage's graph runs.  The stages share one memory pool
+        # (the autograd tape crosses them) and are always replayed in capture order.
+        stages = model._dp_first_stages() if self.dp else [(model._dp_first, (None, None))]
+        self.g_A, self.slices = [], []
+        for run, sl in stages:
+            gk = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gk, **(kw if not self.g_A else dict(kw, pool=self.g_A[0].pool()))):
+                run()
+            self.g_A.append(gk)
+            self.slices.append(sl)
+        with torch.cuda.graph(self.g_B, pool=self.g_A[0].pool(), **kw):
             model._dp_second(warmup)
             if not self.dp:
                 model.optimizer_G.step()
@@ -178,9 +189,13 @@ class GraphedDPStep:
         t_done = side.record_event()
         if self.dp:
             m.finish_pending()                  # wait for the previous step's G bucket, Adam G (eager: one launch)
-        self.g_A.replay()
-        if self.dp:
-            m.dp.reduce(m.optimizer_D)
+        pend = []
+        for gk, (lo, hi) in zip(self.g_A, self.slices):
+            gk.replay()
+            if self.dp:
+                pend.append(m.dp.reduce_slice_async(m.optimizer_D, lo, hi) if lo is not None else m.dp.reduce_async(m.optimizer_D))
+        for w in pend:
+            w.wait()
         main.wait_event(t_done)
         self.g_B.replay()
         m.optimizer_D.note_graph_replay()       # Adam D ran inside g_B

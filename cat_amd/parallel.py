@@ -162,6 +162,14 @@ class DataParallelReducer:
     def reduce(self, optimizer_or_tensors):
         self.reduce_async(optimizer_or_tensors).wait()
 
+    def reduce_slice_async(self, optimizer, lo, hi):
+        """Sum-all-reduce floats [lo, hi) of a one-bucket optimizer's flat gradient buffer (a gradient-ready slice issued while the rest of
+        the backward pass still runs: SURVEY 8e overlap 2).  Ordered behind the CURRENT stream's work at the time of the call."""
+        (bucket,) = optimizer.flat_grads()
+        work = dist.all_reduce(bucket[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        optimizer.grad_scale = 1.0 / self.world_size
+        return PendingReduce([work], optimizer, self.world_size)
+
     def broadcast_parameters(self, modules, src=0):
         """Replicas start identical (DataParallel replicates GPU 0's module every forward).  Conv weights may already live in
         their padded channels_last storage (a strided view): those travel through a dense staging copy."""

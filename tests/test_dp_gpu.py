@@ -320,17 +320,33 @@ def _worker_single_rank_rccl(rank, world, port, q):
         plain.set_input(batches[b])
         plain.optimize_parameters(i)
     eager = H.build_distiller(opt, g['student_shapes'])
-    eager.enable_data_parallel(parallel.DataParallelReducer(), overlap=True)
+    red_e = parallel.DataParallelReducer()
+    events = []       # the order in which backward_D's stages and the D-bucket slices are issued (round 6: sliced D bucket)
+    slice_async = red_e.reduce_slice_async
+    red_e.reduce_slice_async = lambda o, lo, hi: (events.append(('ar', lo, hi)), slice_async(o, lo, hi))[1]
+    eager.enable_data_parallel(red_e, overlap=True)
+    stages_of = eager.backward_D_stages
+
+    def traced_stages():
+        fns, sl = stages_of()
+        return [(lambda k=k, f=f: (events.append(('stage', k)), f())[1]) for k, f in enumerate(fns)], sl
+    eager.backward_D_stages = traced_stages
     for i, b in enumerate(order):
         eager.set_input(batches[b])
         eager.optimize_parameters(i)
     assert eager._pending_G is not None
     eager.finish_pending()
     graphed = H.build_distiller(opt, g['student_shapes'])
-    graphed.enable_data_parallel(parallel.DataParallelReducer(), overlap=True)
+    red_g = parallel.DataParallelReducer()
+    ars = []
+    slice_async_g = red_g.reduce_slice_async
+    red_g.reduce_slice_async = lambda o, lo, hi: (ars.append((lo, hi)), slice_async_g(o, lo, hi))[1]
+    graphed.enable_data_parallel(red_g, overlap=True)
     step = GraphedDPStep(graphed, batches[0], warmup=2)
+    ars.clear()
     for b in order[2:]:
         step(batches[b])
+    nD = eager.optimizer_D._flat[0]['n']
     losses_g = {k: float(v) for k, v in graphed.get_current_losses().items()}      # finish_pending not needed for the loss terms
     graphed.finish_pending()
     torch.cuda.synchronize()
@@ -344,7 +360,8 @@ def _worker_single_rank_rccl(rank, world, port, q):
                losses_plain={k: float(v) for k, v in plain.get_current_losses().items()},
                losses_eager={k: float(v) for k, v in eager.get_current_losses().items()}, losses_graph=losses_g,
                steps=(plain.optimizer_G._flat[0]['step'], eager.optimizer_G._flat[0]['step'], graphed.optimizer_G._flat[0]['step'],
-                      graphed.optimizer_D._flat[0]['step']))
+                      graphed.optimizer_D._flat[0]['step']),
+               events=events, graph_ars=ars, nD=nD, graph_segments=len(step.g_A))
     q.put((0, out))
     torch.distributed.destroy_process_group()
 
@@ -369,3 +386,16 @@ def test_single_rank_rccl_schedule_is_bit_identical_to_plain_step():
         assert out[k] == [], (k, out[k][:5])
     for k, v in out['losses_plain'].items():
         assert out['losses_eager'][k] == v and out['losses_graph'][k] == v, (k, v, out['losses_eager'][k], out['losses_graph'][k])
+    # round 6: the D bucket leaves in THREE gradient-ready slices, each issued right behind the stage that finished it -- the first (the widest
+    # layers' tail of the bucket) while two thirds of backward_D are still to be launched; together they cover the bucket exactly once
+    ev, n_d = out['events'], out['nD']
+    assert len(ev) == 5 * 6
+    for s0 in range(0, len(ev), 6):
+        kinds = [e[0] for e in ev[s0:s0 + 6]]
+        assert kinds == ['stage', 'ar', 'stage', 'ar', 'stage', 'ar'], kinds
+        assert [e[1] for e in ev[s0:s0 + 6:2]] == [0, 1, 2]
+        sl = sorted((e[1], e[2]) for e in ev[s0 + 1:s0 + 6:2])
+        assert sl[0][0] == 0 and sl[-1][1] == n_d and all(a[1] == b[0] for a, b in zip(sl, sl[1:])), sl
+        first = ev[s0 + 1]
+        assert first[2] == n_d and (first[2] - first[1]) > n_d // 2, first      # the tail slice goes first and is the bulk of the bucket
+    assert out['graph_segments'] == 3 and len(out['graph_ars']) == 3 * 3, (out['graph_segments'], out['graph_ars'])
