@@ -84,6 +84,10 @@ class Stage1Geom(C.Structure):
     _fields_ = [(n, c_i) for n in ('N', 'H', 'W', 'xcs', 'cin', 'reflect', 'ycs', 'scs')] + [('col0', c_i * 3), ('width', c_i * 3), ('nvalid', c_i * 3)]
 
 
+class Stage1WGeom(C.Structure):
+    _fields_ = [(n, c_i) for n in ('N', 'H', 'W', 'xcs', 'cin', 'reflect', 'act')] + [('slope', c_f), ('ycs', c_i * 3), ('nvalid', c_i * 3)]
+
+
 class DwmGeom(C.Structure):
     _fields_ = [(n, c_i) for n in ('N', 'H', 'W', 'nq', 'xcs', 'ycs', 'scs', 'sstride', 'reflect', 'act')] + [('slope', c_f), ('ks', c_i * DWM_MAXQ)]
 
@@ -132,6 +136,8 @@ SIGNATURES = {
     'cat_tstage1_supported': (c_i, [c_i, c_i, c_i]),
     'cat_tstage1_fwd': (c_i, [C.POINTER(Stage1Geom), c_p, c_p, c_p, c_p, c_p, c_p]),
     'cat_tstage1_dgrad_supported': (c_i, [c_i, c_i, c_i]),
+    'cat_tstage1w_supported': (c_i, [c_i, c_i, c_i]),
+    'cat_tstage1w_fwd': (c_i, [C.POINTER(Stage1WGeom), c_p, c_p, c_p, c_p, c_p]),
     'cat_tstage1_dgrad': (c_i, [C.POINTER(Stage1Geom), c_p, c_p, c_p, c_p, c_p]),
     'cat_tnorm_finalize': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_i, c_p]),
     'cat_tnorm_finalize2': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_i, c_p]),

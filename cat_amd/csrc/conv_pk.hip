@@ -578,6 +578,169 @@ __global__ __launch_bounds__(256) void tstage1_kernel(const S1Args p) {
   if constexpr (NC > 0) s1_epilogue<NC, STATS>(accC, p, 2, n, tt, oy0, ox0, wave, lr, lq, red);
 }
 
+// ------------------------------------------------------------------------------------------------ frozen teacher: stage 1 in one launch
+// The first convs of an EVAL-mode InvertedResidualChannels block with BatchNorm folded (cat_amd/frozen.py; inception_modules.py:135-165): the
+// 5 x 5 and 3 x 3 convs of the residual branches (256 -> 42 each) and the N-concatenated 1 x 1 convs of the k = 1 residual branch and the three
+// depthwise branches (256 -> 176) from ONE staging of the input tile per 16-channel chunk, epilogue = bias + activation, three output
+// buffers.  Round 6: they were three launches -- two LDS-tile convs staging the same 256-channel input and a 128 x 128-tile GEMM that is
+// overhead-bound at K = 256 (8 chunks per workgroup, 31 % tile padding at N = 176).  Accumulators: (N5 + N3 + N1) x 2 tiles of 16 x 16 per wave;
+// the wide 1 x 1 slot is walked in passes of <= 3 N tiles so that two operand sets stay 24 registers.
+struct S1WArgs {
+  const float* x; const float* pack[3]; const float* bias[3]; float* y[3];
+  int ycs[3], nvalid[3];
+  int xcs, c4, N, H, W, reflect, act;
+  float slope;
+  int hl, tr, tc, tiles_x, tiles;
+};
+
+template <int NT>
+__device__ __forceinline__ void s1w_store(const f4 (&acc)[2][NT], const S1WArgs& p, int k, int t0, int n, int oy0, int ox0, int wave, int lr, int lq) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int oy = oy0 + 2 * wave + i;
+    if (oy >= p.H) continue;
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      const int ox = ox0 + lq * 4 + rg;
+      if (ox >= p.W) continue;
+      float* yo = p.y[k] + (((int64_t)n * p.H + oy) * p.W + ox) * p.ycs[k];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int co = (t0 + j) * 16 + lr;
+        if (co < p.nvalid[k]) yo[co] = cat::apply_act(acc[i][j][rg] + (p.bias[k] ? p.bias[k][co] : 0.f), p.act, p.slope);
+        else if (co < p.ycs[k]) yo[co] = 0.f;
+      }
+    }
+  }
+}
+
+template <int N5, int N3, int N1>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void tstage1w_kernel(const S1WArgs p) {
+  constexpr int MT = 2, TW = 16, MAXIT = ((TH + 4) * (TW + 4) * 4 + 255) / 256;
+  constexpr int P1 = (N1 + 2) / 3, R1 = N1 - 3 * (P1 - 1);      // passes over the 1 x 1 slot, tiles of the last one (1..3)
+  static_assert(N1 >= 1 && N1 <= 12 && N5 >= 1 && N5 <= 3 && N3 >= 1 && N3 <= 3, "tile counts");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tile_floats = p.tr * p.tc * PITCH;
+  float* tile0 = smem;
+  int* tab0 = reinterpret_cast<int*>(smem + 2 * tile_floats);      // [buf][3][TABN]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lq = lane >> 4;
+  const int tt = cat::xcd_remap(blockIdx.x, gridDim.x);
+  const int n = tt / p.tiles, t = tt - n * p.tiles;
+  const int oy0 = (t / p.tiles_x) * TH, ox0 = (t % p.tiles_x) * TW;
+  const int slots = p.tr * p.tc * 4, quad = tid & 3;
+  unsigned soff[MAXIT], smask = 0;
+#pragma unroll
+  for (int it = 0; it < MAXIT; ++it) {
+    const int pix = (tid + it * 256) >> 2;
+    const int r = pix / p.tc;
+    int iy = oy0 - p.hl + r, ix = ox0 - p.hl + (pix - r * p.tc);
+    bool v = tid + it * 256 < slots;
+    if (p.reflect) {
+      v = v && iy > -p.H && iy < 2 * p.H - 1 && ix > -p.W && ix < 2 * p.W - 1;
+      iy = cat::reflect_idx(iy, p.H);
+      ix = cat::reflect_idx(ix, p.W);
+    } else {
+      v = v && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+    }
+    smask |= v ? (1u << it) : 0u;
+    soff[it] = v ? ((unsigned)(n * p.H + iy) * (unsigned)p.W + (unsigned)ix) * (unsigned)p.xcs + quad * 4 : 0u;
+  }
+  f4 sreg[MAXIT];
+  auto gload = [&](int c0) {
+    const bool qv = c0 + quad * 4 < p.c4;
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) sreg[it] = *reinterpret_cast<const f4*>((((smask >> it) & 1u) && qv) ? p.x + soff[it] + c0 : g_zero);
+  };
+  auto sstore = [&](int buf, int c0) {
+    float* tile = tile0 + buf * tile_floats;
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+      const int idx = tid + it * 256;
+      if (idx < slots) *reinterpret_cast<f4*>(tile + (idx >> 2) * PITCH + quad * 4) = sreg[it];
+    }
+    const int nq = min(4, (p.c4 - c0) >> 2);
+    if (tid < TABN) {
+      const int tap = tid / nq, qd = tid - tap * nq;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int ks = k == 0 ? 5 : (k == 1 ? 3 : 1), taps = ks * ks;
+        int off = 0;
+        if (tid < ((taps * nq + 3) >> 2) * 4 && tap < taps) {
+          const int ky = tap / ks, kx = tap - ky * ks, d = p.hl - (ks >> 1);
+          off = ((d + ky) * p.tc + d + kx) * PITCH + qd * 4;
+        }
+        tab0[(buf * 3 + k) * TABN + tid] = off;
+      }
+    }
+  };
+  const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  f4 acc5[MT][N5], acc3[MT][N3], accA[MT][3], accB[MT][3], accC[MT][3], accD[MT][3];      // the 1 x 1 slot: passes A..D of up to 3 tiles
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+#pragma unroll
+    for (int j = 0; j < N5; ++j) acc5[i][j] = zero4;
+#pragma unroll
+    for (int j = 0; j < N3; ++j) acc3[i][j] = zero4;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) accA[i][j] = accB[i][j] = accC[i][j] = accD[i][j] = zero4;
+  }
+  int abase[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) abase[i] = ((2 * wave + i) * p.tc + lr) * PITCH;
+  const __amdgpu_buffer_rsrc_t r5 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.pack[0]), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.pack[1]), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.pack[2]), 0, 0x7fffffff, 0x00020000);
+  unsigned jb5[N5], jb3[N3], jb1[4][3];
+#pragma unroll
+  for (int j = 0; j < N5; ++j) jb5[j] = (unsigned)(j * 64 + lane) * 16u;
+#pragma unroll
+  for (int j = 0; j < N3; ++j) jb3[j] = (unsigned)(j * 64 + lane) * 16u;
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) jb1[q][j] = (unsigned)(min(3 * q + j, N1 - 1) * 64 + lane) * 16u;
+  unsigned so5 = 0, so3 = 0, so1 = 0;     // byte offsets of the current chunk in the three streams
+  gload(0);
+  sstore(0, 0);
+  __syncthreads();
+  int buf = 0;
+  for (int c0 = 0; c0 < p.c4; c0 += 16) {
+    const bool more = c0 + 16 < p.c4;
+    if (more) gload(c0 + 16);
+    const int nq = min(4, (p.c4 - c0) >> 2);
+    const float* tile = tile0 + buf * tile_floats;
+    const int* tab = tab0 + buf * 3 * TABN + lq;
+    {
+      const int ngr = (25 * nq + 3) >> 2;
+      mma_groups<MT, N5>(acc5, tile, tab, abase, r5, jb5, so5, (unsigned)N5 * 1024u, ngr);
+      so5 += (unsigned)ngr * N5 * 1024u;
+    }
+    {
+      const int ngr = (9 * nq + 3) >> 2;
+      mma_groups<MT, N3>(acc3, tile, tab + TABN, abase, r3, jb3, so3, (unsigned)N3 * 1024u, ngr);
+      so3 += (unsigned)ngr * N3 * 1024u;
+    }
+    mma_groups<MT, 3>(accA, tile, tab + 2 * TABN, abase, r1, jb1[0], so1, (unsigned)N1 * 1024u, 1);
+    if constexpr (P1 > 1) mma_groups<MT, 3>(accB, tile, tab + 2 * TABN, abase, r1, jb1[1], so1, (unsigned)N1 * 1024u, 1);
+    if constexpr (P1 > 2) mma_groups<MT, 3>(accC, tile, tab + 2 * TABN, abase, r1, jb1[2], so1, (unsigned)N1 * 1024u, 1);
+    if constexpr (P1 > 3) mma_groups<MT, 3>(accD, tile, tab + 2 * TABN, abase, r1, jb1[3], so1, (unsigned)N1 * 1024u, 1);
+    so1 += (unsigned)N1 * 1024u;
+    if (more) {
+      sstore(buf ^ 1, c0 + 16);
+      __syncthreads();
+      buf ^= 1;
+    }
+  }
+  s1w_store<N5>(acc5, p, 0, 0, n, oy0, ox0, wave, lr, lq);
+  s1w_store<N3>(acc3, p, 1, 0, n, oy0, ox0, wave, lr, lq);
+  s1w_store<3>(accA, p, 2, 0, n, oy0, ox0, wave, lr, lq);
+  if constexpr (P1 > 1) s1w_store<3>(accB, p, 2, 3, n, oy0, ox0, wave, lr, lq);
+  if constexpr (P1 > 2) s1w_store<3>(accC, p, 2, 6, n, oy0, ox0, wave, lr, lq);
+  if constexpr (P1 > 3) s1w_store<3>(accD, p, 2, 9, n, oy0, ox0, wave, lr, lq);
+  (void)R1;
+}
+
 // dst[(G * nt_total + j) * 256 + lane * 4 + e]: G enumerates the MFMA groups of all chunks of one segment in consumption order
 __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ w, float* __restrict__ dst, int mode, int Nn, int Ck, int ks,
                                                    int wcs, int wn, int c4, int nt_total, int64_t total4) {
@@ -767,6 +930,39 @@ int cat_tstage1_fwd(const cat_tstage1_t* g, const float* x, const float* const* 
   float* const ys[3] = {y, y, y};
   const int ycs3[3] = {g->ycs, g->ycs, g->ycs};
   return tstage1_launch(g, x, packs, bias, ys, ycs3, stats, "conv_tstage1", stream);
+}
+
+int cat_tstage1w_supported(int w5, int w3, int w1) {
+  return w5 > 32 && w5 <= 48 && w3 > 32 && w3 <= 48 && w1 > 160 && w1 <= 176;      // the instantiation that exists: 3 + 3 + 11 tiles (m = 42)
+}
+
+int cat_tstage1w_fwd(const cat_tstage1w_t* g, const float* x, const float* const* packs, const float* const* biases, float* const* ys,
+                     cat_stream_t stream) {
+  CAT_REQUIRE(g->N > 0 && g->H > 0 && g->W > 0 && g->cin > 0 && (g->xcs & 3) == 0 && g->xcs >= g->cin, "tstage1w: bad input geometry");
+  CAT_REQUIRE((int64_t)g->N * g->H * g->W * g->xcs < (int64_t)4294967295LL, "tstage1w: source larger than 2^32 elements");
+  CAT_REQUIRE(cat_tstage1w_supported(g->nvalid[0], g->nvalid[1], g->nvalid[2]), "tstage1w: no kernel for %d / %d / %d output channels", g->nvalid[0],
+              g->nvalid[1], g->nvalid[2]);
+  CAT_REQUIRE(!g->reflect || (5 <= g->H && 5 <= g->W), "tstage1w: reflect padding wider than the plane");
+  cat_pk::S1WArgs a{};
+  a.x = x; a.xcs = g->xcs; a.c4 = (g->cin + 3) & ~3; a.N = g->N; a.H = g->H; a.W = g->W; a.reflect = g->reflect; a.act = g->act; a.slope = g->slope;
+  double kflops = 0.0;
+  for (int k = 0; k < 3; ++k) {
+    CAT_REQUIRE(packs[k] && ys[k] && (g->ycs[k] & 3) == 0 && g->ycs[k] >= g->nvalid[k] && g->ycs[k] <= (k == 2 ? 176 : 48), "tstage1w: slot %d", k);
+    a.pack[k] = packs[k]; a.bias[k] = biases ? biases[k] : nullptr; a.y[k] = ys[k]; a.ycs[k] = g->ycs[k]; a.nvalid[k] = g->nvalid[k];
+    const int ks = k == 0 ? 5 : (k == 1 ? 3 : 1);
+    kflops += (double)g->nvalid[k] * ks * ks;
+  }
+  a.hl = 2;
+  a.tr = cat_pk::TH + 4;
+  a.tc = 16 + 4;
+  a.tiles_x = cat::cdiv(g->W, 16);
+  a.tiles = a.tiles_x * cat::cdiv(g->H, cat_pk::TH);
+  const int64_t grid = (int64_t)g->N * a.tiles;
+  CAT_REQUIRE(grid < (int64_t)2147483647, "tstage1w: grid too large");
+  const size_t lds = (size_t)2 * a.tr * a.tc * cat_pk::PITCH * sizeof(float) + 6 * cat_pk::TABN * sizeof(int);
+  cat::ProfScope prof("conv_tstage1w", 2.0 * (double)g->N * g->H * g->W * g->cin * kflops, 0.0, stream);
+  cat_pk::tstage1w_kernel<3, 3, 11><<<(int)grid, 256, lds, (hipStream_t)stream>>>(a);
+  return cat::check_launch("tstage1w_fwd");
 }
 
 int cat_tstage1_supported(int w5, int w3, int w1) {

@@ -19,6 +19,7 @@ instead of 12 convs + 3 activations + add_n(6) + affine + add_n(2): the 42->256 
 and 10 of 18 full-size tensor passes disappear.  One-time weight folding is cached per block (invalidated when a tensor changes).
 InstanceNorm teachers (CycleGAN configs) cannot be folded and take the general path."""
 import ctypes as C
+import os
 
 import torch
 
@@ -26,6 +27,9 @@ from . import _lib as L
 from . import nn as cnn
 from . import ops
 from . import optim
+
+
+_STAGE1W = os.environ.get('CAT_STAGE1W', '1') != '0'      # A/B switch while the kernel is being measured
 
 
 def _affine(bn):
@@ -118,7 +122,9 @@ def _plan(block):
         w2.copy_(last.weight.detach() * s_pw.view(-1, 1, 1, 1))
         if last.bias is not None:
             b_f += last.bias.detach() * s_pw
-        wides.append(dict(op=op, w2=w2, k=last.kernel_size[0]))
+        fconv, fbn = op[1][0], op[1][1]
+        wf, bf = cnn._folded_eval_bn(fconv, fbn, 0)
+        wides.append(dict(op=op, w2=w2, k=last.kernel_size[0], m=fconv.out_channels, wf=wf, bf=bf, act=cnn._act_code(op[1][2])))
     act, slope = cnn._act_code(act_mod)
     # all depthwise convs (+ the copy of the k = 1 residual branch's hidden slice) as ONE launch (cat_dwconv2d_multi_fwd): filters in a 5 x 5
     # frame [25][hc], folded bias, kernel size per channel quad.  The copy is k = 1 with centre weight 1: act(h) = h for an activation
@@ -140,7 +146,14 @@ def _plan(block):
             for q in range(d['off'] // 4, (d['off'] + d['sz']) // 4):
                 ks[q] = k
         dwm = dict(frame=frame.contiguous(), bias=fbias.contiguous(), ks=ks)
-    plan = dict(key=key, tail_pack=None, tail_offs=None, hc=hc, dwm=dwm, w_a=w_a, b_a=b_a.contiguous(), w_f=w_f, b_f=b_f.contiguous(), dws=dws, wides=wides, act=act, slope=slope,
+    # stage 1 in one launch (cat_tstage1w_fwd): one 5 x 5 and one 3 x 3 residual branch + the concatenated 1 x 1 convs, the teacher's widths
+    s1w = None
+    by_k = {wd['k']: wd for wd in wides}
+    if (_STAGE1W and len(wides) == 2 and set(by_k) == {3, 5} and all(wd['act'] == (act, slope) for wd in wides)
+            and L.query('cat_tstage1w_supported', by_k[5]['m'], by_k[3]['m'], hc)):
+        s1w = dict(packs=None, ws=[by_k[5]['wf'], by_k[3]['wf'], w_a],      # packed filter streams: built at the first launch
+                   biases=[by_k[5]['bf'], by_k[3]['bf'], b_a.contiguous()], m=[by_k[5]['m'], by_k[3]['m'], hc])
+    plan = dict(key=key, s1w=s1w, tail_pack=None, tail_offs=None, hc=hc, dwm=dwm, w_a=w_a, b_a=b_a.contiguous(), w_f=w_f, b_f=b_f.contiguous(), dws=dws, wides=wides, act=act, slope=slope,
                 pad_mode=pad_mode, copies=[(o, sz) for (kind, _), (o, m, sz) in zip(slots, offs) if kind == 'res'])
     block._cat_frozen = plan
     return plan
@@ -153,6 +166,17 @@ def block_forward(block, x):
     hc = p['hc']
     m_pix = n * h * w
 
+    def dw_stage(hbuf):
+        # every depthwise conv (+ folded BN + activation) and the k = 1 residual branch's copy as one launch
+        h2 = ops.empty_act(n, hc, h, w, hbuf.device)
+        gm = L.DwMulti()
+        gm.N, gm.H, gm.W, gm.nq, gm.xcs, gm.ycs = n, h, w, hc // 4, hc, hc
+        gm.reflect, gm.act, gm.slope = int(p['pad_mode'] == L.PAD_REFLECT), p['act'], p['slope']
+        for q, k in enumerate(p['dwm']['ks']):
+            gm.ks[q] = k
+        L.call('cat_dwconv2d_multi_fwd', C.byref(gm), ops._p(hbuf), ops._p(p['dwm']['frame']), ops._p(p['dwm']['bias']), ops._p(h2), ops._stream())
+        return h2
+
     def concat_chain(xi):
         # A: every first-level 1x1 conv (+ folded BN + activation) as one GEMM
         stc = ops._stream()
@@ -162,17 +186,12 @@ def block_forward(block, x):
             hbuf = ksum.run(aseg, p['b_a'], ops.empty_act(n, hc, h, w, xi.device), act=p['act'], slope=p['slope'])
         else:
             hbuf = ops.Conv2dFn.apply(xi, p['w_a'], p['b_a'], 1, 0, L.PAD_ZERO, p['act'], p['slope'])
-        h2 = ops.empty_act(n, hc, h, w, xi.device)
         if p['dwm'] is not None:
-            gm = L.DwMulti()
-            gm.N, gm.H, gm.W, gm.nq, gm.xcs, gm.ycs = n, h, w, hc // 4, hc, hc
-            gm.reflect, gm.act, gm.slope = int(p['pad_mode'] == L.PAD_REFLECT), p['act'], p['slope']
-            for q, k in enumerate(p['dwm']['ks']):
-                gm.ks[q] = k
-            L.call('cat_dwconv2d_multi_fwd', C.byref(gm), ops._p(hbuf), ops._p(p['dwm']['frame']), ops._p(p['dwm']['bias']), ops._p(h2), stc)
+            h2 = dw_stage(hbuf)
             if fused_tail:
                 return h2
             return ops.Conv2dFn.apply(h2, p['w_f'], p['b_f'], 1, 0, L.PAD_ZERO, L.ACT_NONE, 0.0)
+        h2 = ops.empty_act(n, hc, h, w, xi.device)
         for o, sz in p['copies']:       # k = 1 res branch: its hidden activation already is the last conv's input
             L.call('cat_slice_channels', ops._p(hbuf), hc, o, sz, C.c_void_p(h2.data_ptr() + 4 * o), hc, m_pix, stc)
         for d in p['dws']:              # depthwise k x k (+ folded BN + activation) on a channel slice of the concatenated buffers
@@ -195,7 +214,24 @@ def block_forward(block, x):
 
     fused_tail = ops.tconv_applicable(n, h, w, c, 3, 3, 1, 1) and 1 + len(p['wides']) <= L.TCONV_MAXSEG
     fns = [concat_chain] + [wide_chain(wd) for wd in p['wides']]
-    if ops.branch_streams_enabled() and len(fns) > 1:
+    s1w = p['s1w'] if fused_tail and p['dwm'] is not None else None
+    if s1w is not None:
+        # every first conv of the block from one staging of x: hid5, hid3 and the concatenated 1 x 1 hidden buffer in one launch
+        if s1w['packs'] is None:
+            from . import tconv
+            s1w['packs'] = [tconv.pack(wt, tconv.FWD) for wt in s1w['ws']]
+        g = L.Stage1WGeom()
+        g.N, g.H, g.W, g.xcs, g.cin = n, h, w, ops.act_cs(x), c
+        g.reflect, g.act, g.slope = int(p['pad_mode'] == L.PAD_REFLECT), p['act'], p['slope']
+        bufs = [ops.empty_act(n, m, h, w, x.device) for m in s1w['m']]
+        for k in range(3):
+            g.ycs[k], g.nvalid[k] = ops.act_cs(bufs[k]), s1w['m'][k]
+        arr = C.c_void_p * 3
+        L.call('cat_tstage1w_fwd', C.byref(g), ops._p(x), arr(*[t.data_ptr() for t in s1w['packs']]), arr(*[t.data_ptr() for t in s1w['biases']]),
+               arr(*[t.data_ptr() for t in bufs]), ops._stream())
+        hid = {5: bufs[0], 3: bufs[1]}
+        outs = [dw_stage(bufs[2])] + [hid[wd['k']] for wd in p['wides']]
+    elif ops.branch_streams_enabled() and len(fns) > 1:
         outs = ops.run_on_side_streams(fns, [x] * len(fns))
     else:
         outs = [fn(x) for fn in fns]

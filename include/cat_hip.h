@@ -461,6 +461,23 @@ int cat_tstage1_fwd(const cat_tstage1_t* g, const float* x, const float* const* 
  * [col0[k], col0[k] + width[k]) of its OWN buffer dxs[k] with pixel stride dxcs[k] (the hidden-activation gradients live in two tensors).
  * g->ycs / scs / reflect are ignored (no statistics, no bias). */
 int cat_tstage1_dgrad_supported(int w5, int w3, int w1);
+/* Stage 1 of an EVAL-mode (frozen, BatchNorm-folded) InvertedResidualChannels block in one launch (round 6; cat_amd/frozen.py): the 5 x 5 and
+ * 3 x 3 first convs of the residual branches and the N-concatenated 1 x 1 first convs of every other branch (inception_modules.py:135-165) from
+ * one staging of the input, y_k = act(conv_k(x) + bias_k) into three buffers -- torch: 6 x F.conv2d + 6 x F.batch_norm + 6 x relu.
+ * packs[k]: cat_tconv_pack streams of the (folded) filters for k = 5, 3, 1; the instantiation that exists serves the teacher's widths
+ * (cat_tstage1w_supported: 42 / 42 / 176 output channels). */
+typedef struct {
+  int N, H, W;
+  int xcs, cin;        /* pixel stride / channels of x */
+  int reflect;         /* padding of the 5 x 5 / 3 x 3 convs: 1 = mirrored, 0 = zero */
+  int act;             /* epilogue activation of all three slots */
+  float slope;
+  int ycs[3];          /* pixel strides of the three outputs (multiples of 4; channels [nvalid, ycs) are written as 0) */
+  int nvalid[3];       /* output channels of the 5 x 5 / 3 x 3 / 1 x 1 slot */
+} cat_tstage1w_t;
+int cat_tstage1w_supported(int w5, int w3, int w1);
+int cat_tstage1w_fwd(const cat_tstage1w_t* g, const float* x, const float* const* packs, const float* const* biases, float* const* ys,
+                     cat_stream_t stream);
 int cat_tstage1_dgrad(const cat_tstage1_t* g, const float* dy, const float* const* packs, float* const* dxs, const int* dxcs,
                       cat_stream_t stream);
 

@@ -105,3 +105,51 @@ def test_ksum_channel_slice_sources(dev):
     torch.cuda.synchronize()
     err = float((y.cpu().double() - want.double()).abs().max() / want.double().abs().max())
     assert err < TOL, err
+
+
+@pytest.mark.parametrize('refl,n,h,w,cin', [(True, 2, 16, 32, 256), (False, 1, 13, 21, 256), (True, 3, 8, 16, 40), (False, 2, 9, 16, 22)])
+def test_teacher_stage1_one_launch_matches_aten(dev, refl, n, h, w, cin):
+    """cat_tstage1w_fwd: the frozen teacher block's first convs -- 5 x 5 and 3 x 3 (-> 42) and the concatenated 1 x 1 convs (-> 176, four
+    42-channel slices in 44-channel slots) -- with bias + ReLU from one staging of x (inception_modules.py:135-165 with eval BatchNorm folded),
+    against F.conv2d per conv on the host.  Ragged planes, zero / mirrored borders, a channel count that is not a multiple of 16 or of 4."""
+    import ctypes as C
+    from cat_amd import _lib as L, ops, tconv
+    g = torch.Generator().manual_seed(99 + h * w + cin)
+    x = torch.randn(n, cin, h, w, generator=g)
+    w5 = torch.randn(42, cin, 5, 5, generator=g) / (cin * 25) ** 0.5
+    w3 = torch.randn(42, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    w1 = torch.zeros(176, cin, 1, 1)
+    b1 = torch.zeros(176)
+    for s in range(4):
+        w1[44 * s:44 * s + 42] = torch.randn(42, cin, 1, 1, generator=g) / cin ** 0.5
+        b1[44 * s:44 * s + 42] = torch.randn(42, generator=g)
+    b5, b3 = torch.randn(42, generator=g), torch.randn(42, generator=g)
+    want = [_ref([x], [wt], refl, b, None, 1) for wt, b in ((w5, b5), (w3, b3), (w1, b1))]
+    assert L.query('cat_tstage1w_supported', 42, 42, 176)
+    packs, keep = [], []
+    for wt in (w5, w3, w1):
+        wd = ops.padded_weight_like(tuple(wt.shape), dev)
+        wd.copy_(wt.to(dev))
+        keep.append(wd)
+        packs.append(tconv.pack(wd, tconv.FWD))
+    xd = ops.to_nhwc(x.to(dev))
+    biases = [b.to(dev) for b in (b5, b3, b1)]
+    ys = [ops.empty_act(n, m, h, w, dev) for m in (42, 42, 176)]
+    for y in ys:
+        y.fill_(float('nan'))
+    geo = L.Stage1WGeom()
+    geo.N, geo.H, geo.W, geo.xcs, geo.cin, geo.reflect, geo.act, geo.slope = n, h, w, ops.act_cs(xd), cin, int(refl), L.ACT_RELU, 0.0
+    for k, m in enumerate((42, 42, 176)):
+        geo.ycs[k], geo.nvalid[k] = ops.act_cs(ys[k]), m
+    arr = C.c_void_p * 3
+    L.call('cat_tstage1w_fwd', C.byref(geo), ops._p(xd), arr(*[t.data_ptr() for t in packs]), arr(*[t.data_ptr() for t in biases]),
+           arr(*[t.data_ptr() for t in ys]), ops._stream())
+    torch.cuda.synchronize()
+    for y, wnt, m in zip(ys, want, (42, 42, 176)):
+        err = float((y.cpu().double() - wnt.double()).abs().max() / wnt.double().abs().max())
+        assert err < TOL, err
+        cs = ops.act_cs(y)
+        raw = torch.as_strided(y, (n, h, w, cs), (h * w * cs, w * cs, cs, 1)).cpu()
+        assert not torch.isnan(raw).any()
+        if cs > m:
+            assert float(raw[..., m:].abs().max()) == 0.0
