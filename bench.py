@@ -212,9 +212,10 @@ def main():
     ap.add_argument('--teacher-side-stream', type=int, default=0, help='c2: run the frozen teacher forward on a side stream (1 GPU)')
     ap.add_argument('--graph', type=int, default=1, help='1 (default): replay the captured step (one hipGraph on 1 GPU; hipGraph segments around '
                                                          'the two collectives with N > 1 ranks, c2 only); 0: eager launches')
-    ap.add_argument('--segments', type=int, default=0,
-                    help='1 GPU, c2 / c3: 1 = replay the step as hipGraph segments with the frozen teacher on a side stream (cat_amd.graph.GraphedDPStep '
-                         'without a reducer) instead of one graph')
+    ap.add_argument('--segments', type=int, default=1,
+                    help='1 GPU, c2 / c3: 1 (default) = replay the step as hipGraph segments with the frozen teacher on a side stream '
+                         '(cat_amd.graph.GraphedDPStep without a reducer: the launch mode of the N > 1 points, minus the collectives; measured '
+                         '+1 %% over one graph, profiles/r06_tconv_ab.txt section 6); 0 = one graph')
     ap.add_argument('--dp-schedule', type=int, default=0, dest='dp_schedule',
                     help='1 GPU only: run the DATA-PARALLEL schedule through a world_size-1 RCCL group (same launch mode as the N > 1 points '
                          'of a scaling curve: teacher on a side stream, bucket all-reduces, deferred Adam G)')
@@ -293,18 +294,20 @@ def main():
     launch = 'eager'
     if args.graph and (dp and not spade and not args.no_overlap or not dp):
         from cat_amd.graph import GraphedDPStep, GraphedStep
-        try:
-            # (the frozen teacher on a side stream INSIDE one captured graph crashes the HIP runtime at capture: --teacher-side-stream with
-            # --graph 1 therefore means the segment schedule, whose teacher graph is replayed on the side stream)
-            seg = (dp or args.segments or args.teacher_side_stream) and not spade
-            graphed = (GraphedDPStep if seg else GraphedStep)(model, batches[0])
-            launch = ('hipGraph segments%s (teacher on a side stream | student fwd + D bwd | Adam D + G bwd)' % (' around the collectives' if dp else '')) \
-                if seg else 'hipGraph replay'
-        except Exception as e:      # a failed capture must not cost the measurement: fall back to eager launches and say so
-            # (deterministic across ranks: every rank captures the same launch sequence, so all of them fall back together)
-            print(f'[bench] hipGraph capture failed ({type(e).__name__}: {e}); timing eager launches', file=sys.stderr, flush=True)
-            graphed = None
-            torch.cuda.synchronize()
+        # (the frozen teacher on a side stream INSIDE one captured graph crashes the HIP runtime at capture: --teacher-side-stream with
+        # --graph 1 therefore means the segment schedule, whose teacher graph is replayed on the side stream)
+        seg = bool((dp or args.segments or args.teacher_side_stream) and not spade)
+        for use_seg in ([True, False] if seg and not dp else [seg]):
+            try:
+                graphed = (GraphedDPStep if use_seg else GraphedStep)(model, batches[0])
+                launch = ('hipGraph segments%s (teacher on a side stream | student fwd + D bwd | Adam D + G bwd)' % (' around the collectives' if dp else '')) \
+                    if use_seg else 'hipGraph replay'
+                break
+            except Exception as e:      # a failed capture must not cost the measurement: fall back (one graph, then eager launches) and say so
+                # (deterministic across ranks: every rank captures the same launch sequence, so all of them fall back together)
+                print(f'[bench] hipGraph capture failed ({type(e).__name__}: {e}); falling back', file=sys.stderr, flush=True)
+                graphed = None
+                torch.cuda.synchronize()
         if graphed is not None:
             def step(i):
                 graphed(batches[i % nbuf])
