@@ -247,6 +247,21 @@ __device__ __forceinline__ void ksum_body(const Args& p) {
     buf ^= 1;
     nq_cur = nq_next;
   }
+  // the residual quads of this lane are fetched behind the last chunk's MFMA stream (64 registers; the budget is 256 at two waves per SIMD):
+  // read in the epilogue they were a round trip in front of the stores (teacher tail: 501 -> 494 us)
+  f4 rr[MT][NT];
+  {
+    const bool rvec = p.res && (p.rcs & 3) == 0 && !(var & 16);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int m = m0 + wm * MT * 16 + i * 16 + lr;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int c0 = n0 + wn * NT * 16 + j * 16 + lq * 4;
+        rr[i][j] = (rvec && m < p.M && c0 + 3 < p.Cout) ? *reinterpret_cast<const f4*>(p.res + (int64_t)m * p.rcs + c0) : f4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  }
   mma(buf, nq_cur);
 
   // epilogue: y = act(acc + bias) + res, four consecutive channels per lane
@@ -268,7 +283,7 @@ __device__ __forceinline__ void ksum_body(const Args& p) {
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = cat::apply_act(v[e], p.act, p.slope);
-        if (ro && !(var & 16)) v += *reinterpret_cast<const f4*>(ro + c0);
+        v += rr[i][j];
         if (!(var & 1) || v[0] == 123.456f) *reinterpret_cast<f4*>(yo + c0) = v;
       } else {
 #pragma unroll
