@@ -614,6 +614,22 @@ __device__ __forceinline__ void s1w_store(const f4 (&acc)[2][NT], const S1WArgs&
   }
 }
 
+template <int NT>
+__device__ __forceinline__ void wload(f4 (&b)[3], const __amdgpu_buffer_rsrc_t rsrc, const unsigned (&jb)[3], unsigned so) {
+#pragma unroll
+  for (int j = 0; j < NT; ++j) b[j] = bload(rsrc, jb[j], so);
+}
+
+template <int MT, int NT>
+__device__ __forceinline__ void wmma(f4 (&acc)[MT][3], const f4 (&a)[MT], const f4 (&b)[3]) {
+#pragma unroll
+  for (int tq = 0; tq < 4; ++tq)
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][tq], b[j][tq], acc[i][j], 0, 0, 0);
+}
+
 template <int N5, int N3, int N1>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void tstage1w_kernel(const S1WArgs p) {
   constexpr int MT = 2, TW = 16, MAXIT = ((TH + 4) * (TW + 4) * 4 + 255) / 256;
@@ -711,6 +727,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int nq = min(4, (p.c4 - c0) >> 2);
     const float* tile = tile0 + buf * tile_floats;
     const int* tab = tab0 + buf * 3 * TABN + lq;
+    f4 bw[3];
+    wload<(P1 == 1 ? R1 : 3)>(bw, r1, jb1[0], so1);
     {
       const int ngr = (25 * nq + 3) >> 2;
       mma_groups<MT, N5>(acc5, tile, tab, abase, r5, jb5, so5, (unsigned)N5 * 1024u, ngr);
@@ -721,10 +739,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       mma_groups<MT, N3>(acc3, tile, tab + TABN, abase, r3, jb3, so3, (unsigned)N3 * 1024u, ngr);
       so3 += (unsigned)ngr * N3 * 1024u;
     }
-    mma_groups<MT, 3>(accA, tile, tab + 2 * TABN, abase, r1, jb1[0], so1, (unsigned)N1 * 1024u, 1);
-    if constexpr (P1 > 1) mma_groups<MT, 3>(accB, tile, tab + 2 * TABN, abase, r1, jb1[1], so1, (unsigned)N1 * 1024u, 1);
-    if constexpr (P1 > 2) mma_groups<MT, 3>(accC, tile, tab + 2 * TABN, abase, r1, jb1[2], so1, (unsigned)N1 * 1024u, 1);
-    if constexpr (P1 > 3) mma_groups<MT, 3>(accD, tile, tab + 2 * TABN, abase, r1, jb1[3], so1, (unsigned)N1 * 1024u, 1);
+    {
+      // the 1 x 1 slot: ONE group per chunk (the centre tap's four quads), N1 tiles wide -- the A fragments are read once, the filter
+      // blocks of pass q + 1 are in flight behind the MFMAs of pass q, those of pass 0 were requested at the top of the chunk
+      f4 aw[MT], bx[3];
+      const int off = tab[2 * TABN];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) aw[i] = *reinterpret_cast<const f4*>(tile + abase[i] + off);
+      if constexpr (P1 > 1) wload<(P1 == 2 ? R1 : 3)>(bx, r1, jb1[1], so1);
+      __builtin_amdgcn_sched_barrier(0);
+      wmma<MT, (P1 == 1 ? R1 : 3)>(accA, aw, bw);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (P1 > 1) {
+        if constexpr (P1 > 2) wload<(P1 == 3 ? R1 : 3)>(bw, r1, jb1[2], so1);
+        __builtin_amdgcn_sched_barrier(0);
+        wmma<MT, (P1 == 2 ? R1 : 3)>(accB, aw, bx);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (P1 > 2) {
+        if constexpr (P1 > 3) wload<R1>(bx, r1, jb1[3], so1);
+        __builtin_amdgcn_sched_barrier(0);
+        wmma<MT, (P1 == 3 ? R1 : 3)>(accC, aw, bw);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (P1 > 3) wmma<MT, R1>(accD, aw, bx);
+    }
     so1 += (unsigned)N1 * 1024u;
     if (more) {
       sstore(buf ^ 1, c0 + 16);
@@ -738,7 +777,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   if constexpr (P1 > 1) s1w_store<3>(accB, p, 2, 3, n, oy0, ox0, wave, lr, lq);
   if constexpr (P1 > 2) s1w_store<3>(accC, p, 2, 6, n, oy0, ox0, wave, lr, lq);
   if constexpr (P1 > 3) s1w_store<3>(accD, p, 2, 9, n, oy0, ox0, wave, lr, lq);
-  (void)R1;
 }
 
 // dst[(G * nt_total + j) * 256 + lane * 4 + e]: G enumerates the MFMA groups of all chunks of one segment in consumption order
