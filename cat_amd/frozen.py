@@ -11,7 +11,8 @@ collapses algebraically -- same values, different evaluation order -- into
     dw  three depthwise convs (+ BN + ReLU in the epilogue) reading / writing channel SLICES of the concatenated buffers
     F   one 1x1 conv  [h_res1 | h_dw1 | h_dw3 | h_dw5] -> C  (the four 42->256 convs as ONE GEMM with K = 176; pw_bn's scale folded
         into its weights, every bias of the block and pw_bn's shift folded into its bias)
-    k>1 res branches keep their first conv (+ BN + ReLU folded); their second convs (pw_bn's scale folded in), F and the skip
+    k>1 res branches keep their first conv (+ BN + ReLU folded) -- with one 5 x 5 and one 3 x 3 branch of the teacher's widths they and A are
+        ONE launch that stages x once per 16-channel chunk (cat_tstage1w_fwd); their second convs (pw_bn's scale folded in), F and the skip
     connection become ONE K-concatenated LDS-tile launch (csrc/conv_pk.hip): out = x + [h | hid3 | hid5] * [F ; W3 ; W5] + bias,
     written once -- on planes too small for that kernel: out = add_n(x, F, k3, k5)
 
@@ -19,7 +20,6 @@ instead of 12 convs + 3 activations + add_n(6) + affine + add_n(2): the 42->256 
 and 10 of 18 full-size tensor passes disappear.  One-time weight folding is cached per block (invalidated when a tensor changes).
 InstanceNorm teachers (CycleGAN configs) cannot be folded and take the general path."""
 import ctypes as C
-import os
 
 import torch
 
@@ -29,7 +29,7 @@ from . import ops
 from . import optim
 
 
-_STAGE1W = os.environ.get('CAT_STAGE1W', '1') != '0'      # A/B switch while the kernel is being measured
+_STAGE1W = True      # stage 1 of the block as one launch (cat_tstage1w_fwd); A/B closed in round 6: teacher forward 11.51 -> 11.15 ms
 
 
 def _affine(bn):
