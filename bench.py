@@ -212,10 +212,10 @@ def main():
     ap.add_argument('--teacher-side-stream', type=int, default=0, help='c2: run the frozen teacher forward on a side stream (1 GPU)')
     ap.add_argument('--graph', type=int, default=1, help='1 (default): replay the captured step (one hipGraph on 1 GPU; hipGraph segments around '
                                                          'the two collectives with N > 1 ranks, c2 only); 0: eager launches')
-    ap.add_argument('--segments', type=int, default=1,
-                    help='1 GPU, c2 / c3: 1 (default) = replay the step as hipGraph segments with the frozen teacher on a side stream '
-                         '(cat_amd.graph.GraphedDPStep without a reducer: the launch mode of the N > 1 points, minus the collectives; measured '
-                         '+1 %% over one graph, profiles/r06_tconv_ab.txt section 6); 0 = one graph')
+    ap.add_argument('--segments', type=int, default=0,
+                    help='1 GPU, c2 / c3: 1 = replay the step as hipGraph segments with the frozen teacher on a side stream (cat_amd.graph.GraphedDPStep '
+                         'without a reducer: the launch mode of the N > 1 points, minus the collectives) instead of one graph.  Measured on one box '
+                         '(profiles/r06_tconv_ab.txt sections 6 - 7): one graph on ONE stream 321.3, segments 320.1 images/s')
     ap.add_argument('--dp-schedule', type=int, default=0, dest='dp_schedule',
                     help='1 GPU only: run the DATA-PARALLEL schedule through a world_size-1 RCCL group (same launch mode as the N > 1 points '
                          'of a scaling curve: teacher on a side stream, bucket all-reduces, deferred Adam G)')

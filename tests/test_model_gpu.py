@@ -163,3 +163,26 @@ def test_frozen_teacher_block_fusion_equals_general_path(dev):
     assert H.rel_err(y_fast.cpu().numpy(), y_ref.cpu().numpy()) < 5e-4      # 9 blocks deep, different (algebraically equal) evaluation order
     T.train()
     assert not frozen.applicable(T.features[0], x)
+
+
+def test_lazy_weight_rehousing_on_a_side_stream_reads_the_live_source(dev):
+    """nn._to_channels_last_ on a stream other than the one the weight was allocated on (the frozen teacher's first forward on the data-parallel
+    schedule's side stream): the old storage must stay out of the allocator's hands until the re-housing copy has executed.  Round 6: without
+    record_stream the construction stream's next allocation recycled it first, and the teacher's late layers were copied from garbage in about
+    half of the two-rank runs.  Here the side stream is kept busy so that the copy is still pending while the main stream recycles."""
+    from cat_amd import nn as cnn
+    conv = cnn.Conv2d(130, 512, 3).to(dev)            # 2.4 MB, Cin 130 -> padded to 132: re-housed at first use
+    ref = conv.weight.detach().clone()
+    big = torch.randn(4096, 4096, device=dev)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        acc = big
+        for _ in range(30):                            # tens of milliseconds of queued work in front of the copy
+            acc = (acc @ big) * 1e-3
+        cnn._to_channels_last_(conv)
+    junk = [torch.full_like(ref, float('nan')) for _ in range(6)]      # main stream: same-size allocations, written at once
+    torch.cuda.synchronize()
+    assert torch.equal(conv.weight.detach(), ref)
+    del junk, acc
