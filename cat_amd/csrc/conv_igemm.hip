@@ -2023,7 +2023,9 @@ static int wgrad32d_nsplit(const cat_conv_t* g, int* rows_per) {
     return 0;
   const int tiles = cdiv(g->Cout, 128) * (g->kh * g->kw * g->Cin / 128);
   const int R = g->N * g->Ho;
-  int ns = cdiv(1024, tiles);
+  // workgroups aimed at: ONE resident round (256 CUs x 2).  Round 6, conv_bench on the three PatchGAN layers: 512 -> 2067 / 555 / 554 us, 1024 (two
+  // rounds, twice the partial-sum traffic) 2155 / 562 / 563, 768 / 1536 / 2048 slower still; with 512 tiles (conv4) the launch writes dw directly
+  int ns = cdiv(512, tiles);
   if (ns > R) ns = R;
   if (ns < 1) ns = 1;
   const int rp = cdiv(R, ns);
