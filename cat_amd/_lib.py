@@ -19,6 +19,13 @@ class ConvGeom(C.Structure):
                                    'pad_mode', 'act')] + [('slope', c_f), ('ycw', c_i), ('wcs', c_i)]
 
 
+class WgradItem(C.Structure):
+    _fields_ = [('g', ConvGeom), ('x', C.c_void_p), ('dy', C.c_void_p), ('dw', C.c_void_p), ('accumulate', c_i)]
+
+
+WGRAD_BATCH_MAX = 8
+
+
 class NormGeom(C.Structure):
     _fields_ = [('N', c_i), ('HW', c_i), ('C', c_i), ('cs', c_i), ('mode', c_i), ('eps', c_f), ('momentum', c_f),
                 ('act', c_i), ('slope', c_f)]
@@ -122,6 +129,8 @@ SIGNATURES = {
     'cat_conv2d_dgrad_ws_bytes': (C.c_size_t, [_G, c_i]),
     'cat_conv2d_dgrad_ws': (c_i, [_G, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p]),
     'cat_conv2d_wgrad': (c_i, [_G, c_p, c_p, c_p, c_i, c_p, c_p]),
+    'cat_conv2d_wgrad_batch_ws_bytes': (C.c_size_t, [C.POINTER(WgradItem), c_i]),
+    'cat_conv2d_wgrad_batch': (c_i, [C.POINTER(WgradItem), c_i, c_p, c_p]),
     'cat_split_bf16': (c_i, [c_p, c_p, c_l, c_p]),
     'cat_conv2d_dgrad_split_applicable': (c_i, [_G]),
     'cat_conv2d_dgrad_split': (c_i, [_G, c_p, c_p, c_p, c_i, c_p]),

@@ -1593,6 +1593,70 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
+// The partial sums of SEVERAL weight gradients reduced by one launch (cat_conv2d_wgrad_batch: the narrow layers of a fused block -- seven
+// 5 - 8 us reduce launches per block were launch latency, not data).  Same arithmetic per item as wgrad_reduce_kernel (same lane / slice
+// order): blocks [start[i], start[i + 1]) serve item i.
+struct RedItem {
+  const float* ws;
+  float* dw;
+  int nsplit, Cout, taps, wlim, wcs, c4, K, accumulate;
+};
+struct RedMany {
+  RedItem it[CAT_WGRAD_BATCH_MAX];
+  int start[CAT_WGRAD_BATCH_MAX + 1];
+  int n;
+};
+
+__device__ __forceinline__ void wgrad_reduce_body(const RedItem& r, int64_t blk, f4* red) {
+  const int cq = r.c4 >> 2;
+  const int64_t total = (int64_t)r.Cout * r.taps * cq;
+  const int64_t e = blk * 16 + (threadIdx.x & 15);
+  const int zl = threadIdx.x >> 4;
+  f4 s = {0.f, 0.f, 0.f, 0.f};
+  int q = 0, tap = 0, co = 0;
+  if (e < total) {
+    q = (int)(e % cq);
+    const int64_t ct = e / cq;
+    tap = (int)(ct % r.taps);
+    co = (int)(ct / r.taps);
+    const float* src = r.ws + (int64_t)co * r.K + tap * r.c4 + q * 4;
+    const int64_t zs = (int64_t)r.Cout * r.K;
+    int z = zl;
+    for (; z + 48 < r.nsplit; z += 64) {
+      const f4 v0 = *reinterpret_cast<const f4*>(src + z * zs), v1 = *reinterpret_cast<const f4*>(src + (z + 16) * zs);
+      const f4 v2 = *reinterpret_cast<const f4*>(src + (z + 32) * zs), v3 = *reinterpret_cast<const f4*>(src + (z + 48) * zs);
+      s += v0;
+      s += v1;
+      s += v2;
+      s += v3;
+    }
+    for (; z < r.nsplit; z += 16) s += *reinterpret_cast<const f4*>(src + z * zs);
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+#pragma unroll
+  for (int st = 8; st >= 1; st >>= 1) {
+    if (zl < st) red[threadIdx.x] += red[threadIdx.x + st * 16];
+    __syncthreads();
+  }
+  if (zl == 0 && e < total) {
+    const f4 v = red[threadIdx.x];
+    float* d = r.dw + ((int64_t)co * r.taps + tap) * r.wcs + q * 4;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (q * 4 + c < r.wlim) d[c] = r.accumulate ? d[c] + v[c] : v[c];
+  }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_many_kernel(const RedMany m) {
+  __shared__ f4 red[256];
+  int i = 0;
+#pragma unroll
+  for (int k = 1; k < CAT_WGRAD_BATCH_MAX; ++k)
+    if (k < m.n && (int)blockIdx.x >= m.start[k]) i = k;
+  wgrad_reduce_body(m.it[i], (int64_t)blockIdx.x - m.start[i], red);
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 // N = 130 .. 192 (the frozen teacher's 176-wide fused GEMM, SPADE's 170-wide heads) fills two 96-wide tiles better than two 128-wide
 // ones (8 % instead of 31 % padding at 176); kept switched off (`on`): the 176-wide layer is the frozen teacher's merged 1 x 1, served by the
@@ -2043,8 +2107,21 @@ size_t cat_conv2d_wgrad_ws_bytes(const cat_conv_t* g) {
   return (size_t)pl.nsplit * g->Cout * K * sizeof(float);
 }
 
-int cat_conv2d_wgrad(const cat_conv_t* g, const float* x, const float* dy, float* dw, int accumulate, void* ws,
-                     cat_stream_t stream) {
+// one weight gradient; `defer` != nullptr: the partial sums stay in ws and *defer describes the reduction still owed (nsplit = 0: none, dw is
+// final) -- cat_conv2d_wgrad_batch reduces several of them with one launch
+static int reduce_or_defer(const RedItem& it, RedItem* defer, hipStream_t s) {
+  if (defer) {
+    *defer = it;
+    return 0;
+  }
+  const int64_t total = (int64_t)it.Cout * it.taps * (it.c4 / 4);
+  wgrad_reduce_kernel<<<(int)((total + 15) / 16), 256, 0, s>>>(it.ws, it.dw, it.nsplit, it.Cout, it.taps, it.wlim, it.wcs, it.c4, it.K, it.accumulate);
+  return cat::check_launch("conv2d_wgrad_reduce");
+}
+
+static int wgrad_impl(const cat_conv_t* g, const float* x, const float* dy, float* dw, int accumulate, void* ws, cat_stream_t stream,
+                      RedItem* defer) {
+  if (defer) defer->nsplit = 0;
   IgemmArgs a{};
   if (int e = fill_common(a, g)) return e;
   const WgradPlan pl = wgrad_plan(g);
@@ -2063,28 +2140,20 @@ int cat_conv2d_wgrad(const cat_conv_t* g, const float* x, const float* dy, float
     const double fl = 2.0 * (double)g->N * g->Ho * g->Wo * g->Cout * g->kh * g->kw * g->Cin;
     cat::ProfScope prof("conv_wgrad_smallco", fl, 0.0, stream);
     if (int e = cat::smallco_wgrad(g, x, dy, (float*)ws, s)) return e;
-    const int64_t total = (int64_t)a.Cout * a.kh * a.kw * (a.c4 / 4);
-    wgrad_reduce_kernel<<<(int)((total + 15) / 16), 256, 0, s>>>((const float*)ws, dw, cat::smallco_wgrad_nblk(g), a.Cout, a.kh * a.kw,
-                                                                  a.cval, a.wcs, a.c4, a.K, accumulate);
-    return cat::check_launch("conv2d_wgrad_reduce");
+    return reduce_or_defer(RedItem{(const float*)ws, dw, cat::smallco_wgrad_nblk(g), a.Cout, a.kh * a.kw, a.cval, a.wcs, a.c4, a.K, accumulate}, defer, s);
   }
   const double prof_flops = 2.0 * (double)g->N * g->Ho * g->Wo * g->Cout * g->kh * g->kw * g->Cin;
   if (cat::twgrad_applicable(g)) {
     CAT_REQUIRE(ws != nullptr, "conv wgrad: workspace required");
     cat::ProfScope prof("conv_twgrad", prof_flops, 0.0, stream);
     if (int e = cat::twgrad(g, x, dy, (float*)ws, s)) return e;
-    const int64_t total = (int64_t)a.Cout * a.kh * a.kw * (a.c4 / 4);
-    wgrad_reduce_kernel<<<(int)((total + 15) / 16), 256, 0, s>>>((const float*)ws, dw, cat::twgrad_nblk(g), a.Cout, a.kh * a.kw, a.cval, a.wcs, a.c4,
-                                                                  a.K, accumulate);
-    return cat::check_launch("conv2d_wgrad_reduce");
+    return reduce_or_defer(RedItem{(const float*)ws, dw, cat::twgrad_nblk(g), a.Cout, a.kh * a.kw, a.cval, a.wcs, a.c4, a.K, accumulate}, defer, s);
   }
   if (cat::pwgrad_applicable(g)) {
     CAT_REQUIRE(ws != nullptr, "conv wgrad: workspace required");
     cat::ProfScope prof("conv_pwgrad", prof_flops, 0.0, stream);
     if (int e = cat::pwgrad(g, x, dy, (float*)ws, s)) return e;
-    const int64_t total = (int64_t)a.Cout * (a.c4 / 4);
-    wgrad_reduce_kernel<<<(int)((total + 15) / 16), 256, 0, s>>>((const float*)ws, dw, cat::pwgrad_nblk(g), a.Cout, 1, a.cval, a.wcs, a.c4, a.K, accumulate);
-    return cat::check_launch("conv2d_wgrad_reduce");
+    return reduce_or_defer(RedItem{(const float*)ws, dw, cat::pwgrad_nblk(g), a.Cout, 1, a.cval, a.wcs, a.c4, a.K, accumulate}, defer, s);
   }
   int rows_per = 0;
   if (const int nsd = wgrad32d_nsplit(g, &rows_per)) {
@@ -2102,10 +2171,7 @@ int cat_conv2d_wgrad(const cat_conv_t* g, const float* x, const float* dy, float
     }
     if (int e = cat::check_launch("conv2d_wgrad")) return e;
     if (!a.direct) {
-      const int64_t total = (int64_t)a.Cout * a.kh * a.kw * (a.c4 / 4);
-      wgrad_reduce_kernel<<<(int)((total + 15) / 16), 256, 0, s>>>((const float*)ws, dw, nsd, a.Cout, a.kh * a.kw, a.cval, a.wcs, a.c4, a.K,
-                                                                    accumulate);
-      return cat::check_launch("conv2d_wgrad_reduce");
+      return reduce_or_defer(RedItem{(const float*)ws, dw, nsd, a.Cout, a.kh * a.kw, a.cval, a.wcs, a.c4, a.K, accumulate}, defer, s);
     }
     return 0;
   }
@@ -2125,12 +2191,44 @@ int cat_conv2d_wgrad(const cat_conv_t* g, const float* x, const float* dy, float
 #undef LAUNCH
   if (int e = cat::check_launch("conv2d_wgrad")) return e;
   if (!a.direct) {
-    const int64_t total = (int64_t)a.Cout * a.kh * a.kw * (a.c4 / 4);
-    const int grid = (int)((total + 15) / 16);
-    wgrad_reduce_kernel<<<grid, 256, 0, s>>>((const float*)ws, dw, pl.nsplit, a.Cout, a.kh * a.kw, a.cval, a.wcs, a.c4, a.K, accumulate);
-    return cat::check_launch("conv2d_wgrad_reduce");
+    return reduce_or_defer(RedItem{(const float*)ws, dw, pl.nsplit, a.Cout, a.kh * a.kw, a.cval, a.wcs, a.c4, a.K, accumulate}, defer, s);
   }
   return 0;
+}
+
+int cat_conv2d_wgrad(const cat_conv_t* g, const float* x, const float* dy, float* dw, int accumulate, void* ws,
+                     cat_stream_t stream) {
+  return wgrad_impl(g, x, dy, dw, accumulate, ws, stream, nullptr);
+}
+
+size_t cat_conv2d_wgrad_batch_ws_bytes(const cat_wgrad_item_t* items, int n) {
+  size_t total = 0;
+  for (int i = 0; i < n; ++i) total += (cat_conv2d_wgrad_ws_bytes(&items[i].g) + 255) & ~(size_t)255;
+  return total;
+}
+
+int cat_conv2d_wgrad_batch(const cat_wgrad_item_t* items, int n, void* ws, cat_stream_t stream) {
+  CAT_REQUIRE(n >= 1 && n <= CAT_WGRAD_BATCH_MAX, "conv wgrad batch: 1 .. %d items", CAT_WGRAD_BATCH_MAX);
+  CAT_REQUIRE(ws != nullptr, "conv wgrad batch: workspace required");
+  RedMany many{};
+  size_t off = 0;
+  int blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    RedItem it{};
+    if (int e = wgrad_impl(&items[i].g, items[i].x, items[i].dy, items[i].dw, items[i].accumulate, (char*)ws + off, stream, &it)) return e;
+    off += (cat_conv2d_wgrad_ws_bytes(&items[i].g) + 255) & ~(size_t)255;
+    if (it.nsplit > 0) {
+      many.it[many.n] = it;
+      many.start[many.n] = blocks;
+      const int64_t total = (int64_t)it.Cout * it.taps * (it.c4 / 4);
+      blocks += (int)((total + 15) / 16);
+      ++many.n;
+    }
+  }
+  if (many.n == 0) return 0;
+  many.start[many.n] = blocks;
+  wgrad_reduce_many_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(many);
+  return cat::check_launch("conv2d_wgrad_reduce_many");
 }
 
 }  // extern "C"

@@ -518,6 +518,29 @@ class _BlockFn(torch.autograd.Function):
                 grads[id(param)] = ops._write_param_grad(param, lambda dst_, acc: kernel(dst_, acc, ops._stream()))
             side.run(job)
 
+        # one stream (the inception distillers' default): the weight-gradient producers run back to back at the end and their partial sums
+        # are reduced by ONE launch (ops.WgradBatch); with side streams on they stay separate jobs
+        batch = None if ops.branch_streams_enabled() else ops.WgradBatch(dev, grads)
+
+        def put_wgrad(param, make):      # make(dst) -> (geometry, x pointer, dy pointer)
+            if batch is not None:
+                return batch.add(param, make)
+
+            def kernel(dst_, acc, sst):
+                gw, xp, dyp = make(dst_)
+                ws = ops.workspace(L.query('cat_conv2d_wgrad_ws_bytes', C.byref(gw)), dev)
+                L.call('cat_conv2d_wgrad', C.byref(gw), xp, dyp, ops._p(dst_), acc, ops._p(ws), sst)
+            put_side(param, kernel)
+
+        def put_wgrad_into(dst, geom, xp, dyp):      # merged launches: destination = a gradient view of the plan, overwritten
+            if batch is not None:
+                return batch.add_into(dst, 0, geom, xp, dyp)
+
+            def job():
+                ws = ops.workspace(L.query('cat_conv2d_wgrad_ws_bytes', C.byref(geom)), dev)
+                L.call('cat_conv2d_wgrad', C.byref(geom), xp, dyp, ops._p(dst), 0, ops._p(ws), ops._stream())
+            side.run(job)
+
         # ---- 1. pw_bn: dT from dy (the skip connection's share of dy is added at the very end)
         pw = block.pw_bn
         if ops.act_cs(dy) != p.cs:
@@ -557,12 +580,10 @@ class _BlockFn(torch.autograd.Function):
             mode2 = pad_mode if pad2 > 0 else L.PAD_ZERO
             conv2 = b['conv2']
 
-            def kw(dst_, acc, sst, xptr=xptr, m=m, scs_=scs_, k2=k2, pad2=pad2, mode2=mode2):
-                gw = ops._conv_geom(n, h, w, m, scs_, h, w, c, p.cs, k2, k2, 1, pad2, mode2, wcs=ops._grad_wcs(dst_))
-                ws = ops.workspace(L.query('cat_conv2d_wgrad_ws_bytes', C.byref(gw)), dev)
-                L.call('cat_conv2d_wgrad', C.byref(gw), xptr, ops._p(dt), ops._p(dst_), acc, ops._p(ws), sst)
+            def kw(dst_, xptr=xptr, m=m, scs_=scs_, k2=k2, pad2=pad2, mode2=mode2):
+                return ops._conv_geom(n, h, w, m, scs_, h, w, c, p.cs, k2, k2, 1, pad2, mode2, wcs=ops._grad_wcs(dst_)), xptr, ops._p(dt)
             if res or not p.merge2:
-                put_side(conv2.weight, kw)
+                put_wgrad(conv2.weight, kw)
             if not res and p.dpack2_dw is not None:
                 continue            # input gradient: the merged launch below
             seg_pad = k2 - 1 - (0 if mode2 == L.PAD_REFLECT else pad2)
@@ -577,11 +598,7 @@ class _BlockFn(torch.autograd.Function):
             seg = tconv.Segment(None, 1, 0, False, 0, c4=p.cs, cin=c, xcs=p.cs, ptr=dt.data_ptr())
             tconv.run([seg], p.dpack2_dw, None, None, p.hcd, n, h, w, h, w, ycs=p.hcd, ycw=p.hcd, yptr=dad.data_ptr(), nvalid=sum(b['m'] for b in p.dws))
         if p.merge2:      # d W2 of all depthwise branches: dT^T x Ad as ONE 1x1 weight-gradient launch over the concatenated hidden buffer
-            def kw2(sst):
-                gw = ops._conv_geom(n, h, w, p.hcd, p.hcd, h, w, c, p.cs, 1, 1, 1, 0, L.PAD_ZERO, wcs=p.hcd)
-                ws = ops.workspace(L.query('cat_conv2d_wgrad_ws_bytes', C.byref(gw)), dev)
-                L.call('cat_conv2d_wgrad', C.byref(gw), ops._p(ad), ops._p(dt), ops._p(p.gv['w2']), 0, ops._p(ws), sst)
-            side.run(lambda: kw2(ops._stream()))
+            put_wgrad_into(p.gv['w2'], ops._conv_geom(n, h, w, p.hcd, p.hcd, h, w, c, p.cs, 1, 1, 1, 0, L.PAD_ZERO, wcs=p.hcd), ops._p(ad), ops._p(dt))
         if p.has_bias2:
             _channel_sum(dt, m_pix, c, p.cs, p.gv['c2'])
         # ---- 4. / 5. depthwise stage
@@ -637,11 +654,8 @@ class _BlockFn(torch.autograd.Function):
         if p.merge1 is not None:
             g1 = p.merge1
 
-            def kw1m(sst):
-                gw = ops._conv_geom(n, h, w, c, p.cs, h, w, g1['width'], p.hc1, 1, 1, 1, 0, L.PAD_ZERO, wcs=p.cs)
-                ws = ops.workspace(L.query('cat_conv2d_wgrad_ws_bytes', C.byref(gw)), dev)
-                L.call('cat_conv2d_wgrad', C.byref(gw), ops._p(x), C.c_void_p(dz1.data_ptr() + 4 * g1['off']), ops._p(p.gv['w1']), 0, ops._p(ws), sst)
-            side.run(lambda: kw1m(ops._stream()))
+            put_wgrad_into(p.gv['w1'], ops._conv_geom(n, h, w, c, p.cs, h, w, g1['width'], p.hc1, 1, 1, 1, 0, L.PAD_ZERO, wcs=p.cs), ops._p(x),
+                           C.c_void_p(dz1.data_ptr() + 4 * g1['off']))
         for b in p.branches:
             if p.merge1 is not None and b['k'] == 1:
                 continue
@@ -650,11 +664,11 @@ class _BlockFn(torch.autograd.Function):
             mode1 = pad_mode if pad1 > 0 else L.PAD_ZERO
             dyp = C.c_void_p(dz1.data_ptr() + 4 * b['o1'])
 
-            def kw1(dst_, acc, sst, dyp=dyp, m=m, k=k, pad1=pad1, mode1=mode1):
-                gw = ops._conv_geom(n, h, w, c, p.cs, h, w, m, p.hc1, k, k, 1, pad1, mode1, wcs=ops._grad_wcs(dst_))
-                ws = ops.workspace(L.query('cat_conv2d_wgrad_ws_bytes', C.byref(gw)), dev)
-                L.call('cat_conv2d_wgrad', C.byref(gw), ops._p(x), dyp, ops._p(dst_), acc, ops._p(ws), sst)
-            put_side(b['conv1'].weight, kw1)
+            def kw1(dst_, dyp=dyp, m=m, k=k, pad1=pad1, mode1=mode1):
+                return ops._conv_geom(n, h, w, c, p.cs, h, w, m, p.hc1, k, k, 1, pad1, mode1, wcs=ops._grad_wcs(dst_)), ops._p(x), dyp
+            put_wgrad(b['conv1'].weight, kw1)
+        if batch is not None:
+            batch.flush()
         # ---- 8. first convs: the six input gradients as ONE K-concatenated launch (+ the skip connection's gradient)
         dx = None
         if ctx.needs_input_grad[0]:

@@ -67,6 +67,19 @@ int cat_conv2d_dgrad_t(const cat_conv_t* g, const float* dy, const float* w, con
 size_t cat_conv2d_wgrad_ws_bytes(const cat_conv_t* g);
 int cat_conv2d_wgrad(const cat_conv_t* g, const float* x, const float* dy, float* dw, int accumulate, void* ws,
                      cat_stream_t stream);
+/* Several weight gradients whose partial sums are reduced by ONE launch (the narrow layers of a fused block: seven 5 - 8 us reduce launches
+ * per block were launch latency).  Item i uses its own region of `ws` (cat_conv2d_wgrad_batch_ws_bytes); results are bit-identical to n
+ * cat_conv2d_wgrad calls (same kernels, same summation order). */
+#define CAT_WGRAD_BATCH_MAX 8
+typedef struct {
+  cat_conv_t g;
+  const float* x;
+  const float* dy;
+  float* dw;
+  int accumulate;
+} cat_wgrad_item_t;
+size_t cat_conv2d_wgrad_batch_ws_bytes(const cat_wgrad_item_t* items, int n);
+int cat_conv2d_wgrad_batch(const cat_wgrad_item_t* items, int n, void* ws, cat_stream_t stream);
 /* Split-K variants for layers whose output tile grid cannot fill 256 CUs (few pixels, very deep reduction: the 4x8 .. 32x64
  * blocks of the SPADE generators, inception_spade_generator.py:63-124; PatchGAN's 1024 -> 1 head, discriminators.py:72-74, whose
  * input channels are cut into slices).  *_ws_bytes returns 0 when the plain entry point is the right one; otherwise the caller

@@ -113,7 +113,7 @@ def test_qconv_structs_match_their_ctypes_mirrors(tmp_path):
     import ctypes as C
     import subprocess
     structs = {'cat_qseg_t': _lib.QSeg, 'cat_qconv_t': _lib.QConv, 'cat_qplan_t': _lib.QPlan, 'cat_tseg_t': _lib.TSeg, 'cat_tconv_t': _lib.TConv,
-               'cat_nslice_t': _lib.NSlice, 'cat_ksum_seg_t': _lib.KSeg, 'cat_ksum_t': _lib.KSum, 'cat_dwmulti_t': _lib.DwMulti, 'cat_tstage1w_t': _lib.Stage1WGeom}
+               'cat_nslice_t': _lib.NSlice, 'cat_ksum_seg_t': _lib.KSeg, 'cat_ksum_t': _lib.KSum, 'cat_dwmulti_t': _lib.DwMulti, 'cat_tstage1w_t': _lib.Stage1WGeom, 'cat_wgrad_item_t': _lib.WgradItem}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "cat_hip.h"', 'int main(void) {']
     for cname, cls in structs.items():
         lines.append(f'  printf("{cname} size %zu\\n", sizeof({cname}));')
