@@ -612,3 +612,40 @@ def test_block_with_replicate_padding_and_relu6(dev):
     assert rel(y, yr) < 1e-4
     y.backward(_nhwc(gy, dev))
     assert rel(xg.grad, xr.grad) < 5e-4
+
+
+def test_wgrad_batch_equals_separate_calls(dev):
+    """cat_conv2d_wgrad_batch (ops.WgradBatch): several weight gradients with ONE reduce launch for their partial sums must be bit-identical to
+    one cat_conv2d_wgrad call each -- same producer kernels, same summation order (the fused block's seven narrow layers; here one layer per
+    producer family: 1 x 1 pixel-split, LDS-tile 5 x 5 and 3 x 3, the generic split, and a direct single-slice launch), with and without
+    accumulation into an existing gradient."""
+    import ctypes as C
+    from cat_amd import _lib as L, ops
+    g = torch.Generator().manual_seed(5)
+    n, h, w = 4, 32, 32
+    layers = [(77, 15, 1, 0), (77, 18, 5, 1), (77, 12, 3, 1), (40, 130, 3, 0), (8, 8, 3, 0)]      # Cin, Cout, k, reflect
+    xs, dys, dsts_a, dsts_b, geoms = [], [], [], [], []
+    for cin, cout, k, refl in layers:
+        x = ops.to_nhwc(torch.randn(n, cin, h, w, generator=g).to(dev))
+        dy = ops.to_nhwc(torch.randn(n, cout, h, w, generator=g).to(dev))
+        wa = ops.padded_weight_like((cout, cin, k, k), dev)
+        wa.copy_(torch.randn(cout, cin, k, k, generator=g).to(dev))          # the gradient already in the buffer (accumulate = 1 for odd layers)
+        wb = ops.padded_weight_like((cout, cin, k, k), dev)
+        wb.copy_(wa)
+        geoms.append(ops._conv_geom(n, h, w, cin, ops.act_cs(x), h, w, cout, ops.act_cs(dy), k, k, 1, k // 2, L.PAD_REFLECT if refl else L.PAD_ZERO,
+                                    wcs=ops._grad_wcs(wa)))
+        xs.append(x); dys.append(dy); dsts_a.append(wa); dsts_b.append(wb)
+    for i, gw in enumerate(geoms):
+        ws = ops.workspace(L.query('cat_conv2d_wgrad_ws_bytes', C.byref(gw)), dev)
+        L.call('cat_conv2d_wgrad', C.byref(gw), ops._p(xs[i]), ops._p(dys[i]), ops._p(dsts_a[i]), i & 1, ops._p(ws), ops._stream())
+    batch = ops.WgradBatch(dev, {})
+    for i, gw in enumerate(geoms):
+        batch.add_into(dsts_b[i], i & 1, gw, ops._p(xs[i]), ops._p(dys[i]))
+    batch.flush()
+    torch.cuda.synchronize()
+    for a, b, lay in zip(dsts_a, dsts_b, layers):
+        assert torch.equal(torch.as_strided(a, (a.untyped_storage().nbytes() // 4,), (1,), 0), torch.as_strided(b, (b.untyped_storage().nbytes() // 4,), (1,), 0)), lay
+    # and against ATen for the one written fresh with zero padding (even index: accumulate = 0)
+    want = torch.nn.functional.conv2d(ops.to_nchw(xs[4]).cpu().transpose(0, 1), ops.to_nchw(dys[4]).cpu().transpose(0, 1), padding=1).transpose(0, 1)
+    got = dsts_b[4].cpu()
+    assert float((got.double() - want.double()).abs().max() / want.double().abs().max()) < 1e-4
