@@ -67,27 +67,55 @@ __global__ __launch_bounds__(256) void gram_kernel(const float* __restrict__ X, 
 }
 
 // ws layout (floats): [0..3] sxy, sxx, syy, ka | Gx[N*N] | Gy[N*N] | partX[nb][NN*NN] | partY[nb][NN*NN]
-// stage 1: Gx / Gy entries = sum of the per-workgroup partials; 64 entries x 4 partial-lanes per workgroup
+// stage 1: Gx / Gy entries = sum of the per-workgroup partials; 16 entries x 16 partial-lanes per workgroup, four independent loads per lane and
+// step, lanes combined pairwise through LDS in a fixed order (round 6: 64 entries x 4 lanes = 4 workgroups walked 2 x 128 dependent loads
+// per lane: 43 us per loss term for 2 MB of partials)
 __global__ __launch_bounds__(256) void ka_gram_reduce_kernel(float* __restrict__ ws, int N, int NN, int nbx, int nby) {
   __shared__ float red[2][256];
   float* Gx = ws + 4;
   float* Gy = Gx + N * N;
   const float* px = Gy + N * N;
   const float* py = px + (int64_t)nbx * NN * NN;
-  const int e = blockIdx.x * 64 + (threadIdx.x & 63), zl = threadIdx.x >> 6;
+  const int e = blockIdx.x * 16 + (threadIdx.x & 15), zl = threadIdx.x >> 4;
   float gx = 0.f, gy = 0.f;
   if (e < N * N) {
     const int i = e / N, j = e - i * N;
-    for (int b = zl; b < nbx; b += 4) gx += px[(int64_t)b * NN * NN + i * NN + j];
-    for (int b = zl; b < nby; b += 4) gy += py[(int64_t)b * NN * NN + i * NN + j];
+    const int64_t zs = (int64_t)NN * NN;
+    const float* sx = px + i * NN + j;
+    const float* sy = py + i * NN + j;
+    int b = zl;
+    for (; b + 48 < nbx; b += 64) {
+      const float v0 = sx[b * zs], v1 = sx[(b + 16) * zs], v2 = sx[(b + 32) * zs], v3 = sx[(b + 48) * zs];
+      gx += v0;
+      gx += v1;
+      gx += v2;
+      gx += v3;
+    }
+    for (; b < nbx; b += 16) gx += sx[b * zs];
+    b = zl;
+    for (; b + 48 < nby; b += 64) {
+      const float v0 = sy[b * zs], v1 = sy[(b + 16) * zs], v2 = sy[(b + 32) * zs], v3 = sy[(b + 48) * zs];
+      gy += v0;
+      gy += v1;
+      gy += v2;
+      gy += v3;
+    }
+    for (; b < nby; b += 16) gy += sy[b * zs];
   }
   red[0][threadIdx.x] = gx;
   red[1][threadIdx.x] = gy;
   __syncthreads();
+#pragma unroll
+  for (int st = 8; st >= 1; st >>= 1) {
+    if (zl < st) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + st * 16];
+      red[1][threadIdx.x] += red[1][threadIdx.x + st * 16];
+    }
+    __syncthreads();
+  }
   if (zl == 0 && e < N * N) {
-    const int l = threadIdx.x;
-    Gx[e] = (red[0][l] + red[0][l + 64]) + (red[0][l + 128] + red[0][l + 192]);
-    Gy[e] = (red[1][l] + red[1][l + 64]) + (red[1][l + 128] + red[1][l + 192]);
+    Gx[e] = red[0][threadIdx.x];
+    Gy[e] = red[1][threadIdx.x];
   }
 }
 
@@ -276,7 +304,7 @@ int cat_ka_fwd(const float* X, int64_t Dx, const float* Y, int64_t Dy, int N, fl
   hipStream_t s = (hipStream_t)stream;
   if (int e = launch_gram(X, Dx, N, partx, px, s)) return e;
   if (int e = launch_gram(Y, Dy, N, party, py, s)) return e;
-  ka_gram_reduce_kernel<<<cdiv(N * N, 64), 256, 0, s>>>(w, N, px.NN, px.nb, py.nb);
+  ka_gram_reduce_kernel<<<cdiv(N * N, 16), 256, 0, s>>>(w, N, px.NN, px.nb, py.nb);
   ka_finalize_kernel<<<1, 256, 0, s>>>(w, N, out);
   return cat::check_launch("ka_finalize");
 }
