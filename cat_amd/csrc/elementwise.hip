@@ -167,20 +167,33 @@ __global__ __launch_bounds__(256) void chansum_partial_kernel(const float* __res
     *reinterpret_cast<f4*>(part + (int64_t)b * cs + cq * 4) = s;
   }
 }
+// 16 channels x 16 partial lanes per workgroup, four independent loads per lane and step, lanes combined pairwise through LDS in a fixed order
+// (round 6: 64 channels x 4 lanes walked up to 128 dependent loads per lane: 16 us for 64 KB of partials)
 __global__ __launch_bounds__(256) void chansum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int C, int cs, int nb,
                                                             int accumulate) {
   __shared__ float red[256];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63), zl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 16 + (threadIdx.x & 15), zl = threadIdx.x >> 4;
   float s = 0.f;
-  if (c < C)
-    for (int b = zl; b < nb; b += 4) s += part[(int64_t)b * cs + c];
+  if (c < C) {
+    const float* src = part + c;
+    int b = zl;
+    for (; b + 48 < nb; b += 64) {
+      const float v0 = src[(int64_t)b * cs], v1 = src[(int64_t)(b + 16) * cs], v2 = src[(int64_t)(b + 32) * cs], v3 = src[(int64_t)(b + 48) * cs];
+      s += v0;
+      s += v1;
+      s += v2;
+      s += v3;
+    }
+    for (; b < nb; b += 16) s += src[(int64_t)b * cs];
+  }
   red[threadIdx.x] = s;
   __syncthreads();
-  if (zl == 0 && c < C) {
-    const int l = threadIdx.x;
-    s = (red[l] + red[l + 64]) + (red[l + 128] + red[l + 192]);
-    out[c] = accumulate ? out[c] + s : s;
+#pragma unroll
+  for (int st = 8; st >= 1; st >>= 1) {
+    if (zl < st) red[threadIdx.x] += red[threadIdx.x + st * 16];
+    __syncthreads();
   }
+  if (zl == 0 && c < C) out[c] = accumulate ? out[c] + red[threadIdx.x] : red[threadIdx.x];
 }
 
 struct CsPlan { int nq, nz, zq, ppl, nb; };
@@ -394,7 +407,7 @@ int cat_channel_sum(const float* x, int M, int C, int cs, float* out, int accumu
   const CsPlan p = cs_plan(M, cs);
   hipStream_t s = (hipStream_t)stream;
   chansum_partial_kernel<<<dim3(p.nb, p.nz), 256, 0, s>>>(x, (float*)ws, M, cs, p.zq, p.ppl, p.nb);
-  chansum_final_kernel<<<cdiv(C, 64), 256, 0, s>>>((const float*)ws, out, C, cs, p.nb, accumulate);
+  chansum_final_kernel<<<cdiv(C, 16), 256, 0, s>>>((const float*)ws, out, C, cs, p.nb, accumulate);
   return cat::check_launch("channel_sum");
 }
 
