@@ -1,6 +1,7 @@
 // HBM-bound elementwise / layout / optimizer kernels (gfx950).  All of them move float4 per lane over flat NHWC
 // buffers (pixel stride is a multiple of 4 floats) and grid-stride over at most 8192 workgroups.
 #include "common.h"
+#include <stdint.h>
 
 namespace {
 using cat::cdiv;
@@ -79,6 +80,20 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
   for (int j = ty; j < 64; j += 4) {
     const int p = p0 + j, c = c0 + tx;
     if (p < HW && c < ycs) y[((int64_t)n * HW + p) * ycs + c] = tile[tx][j];
+  }
+}
+
+// C <= 4 into a 4-wide pixel stride (the RGB batches of set_input): one lane per pixel, C coalesced plane reads, one float4 store -- the
+// 64 x 64 tile transpose above spends 61 of 64 rows / lanes on padding there (36 us for a 16 x 3 x 256 x 256 batch; this form: HBM time)
+__global__ __launch_bounds__(256) void nchw_to_nhwc4_kernel(const float* __restrict__ x, float* __restrict__ y, int C, int HW, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t n = i / HW;
+    const int p = (int)(i - n * HW);
+    f4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (e < C) v[e] = x[(n * C + e) * HW + p];
+    *reinterpret_cast<f4*>(y + i * 4) = v;
   }
 }
 
@@ -350,6 +365,11 @@ int cat_slice_channels(const float* x, int xcs, int c0, int c, float* y, int ycs
 int cat_nchw_to_nhwc(const float* x, float* y, int N, int C, int H, int W, int ycs, cat_stream_t stream) {
   cat::ProfScope prof("layout", 0.0, 8.0 * N * C * H * W, stream);
   CAT_REQUIRE(ycs >= C, "nchw_to_nhwc: ycs < C");
+  if (ycs == 4 && (reinterpret_cast<uintptr_t>(y) & 15) == 0) {
+    const int64_t total = (int64_t)N * H * W;
+    nchw_to_nhwc4_kernel<<<ew_grid(total), 256, 0, (hipStream_t)stream>>>(x, y, C, H * W, total);
+    return cat::check_launch("nchw_to_nhwc");
+  }
   dim3 grid(cdiv(H * W, 64), cdiv(ycs, 64), N);
   nchw_to_nhwc_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, y, C, H * W, ycs);
   return cat::check_launch("nchw_to_nhwc");

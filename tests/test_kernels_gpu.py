@@ -649,3 +649,18 @@ def test_wgrad_batch_equals_separate_calls(dev):
     want = torch.nn.functional.conv2d(ops.to_nchw(xs[4]).cpu().transpose(0, 1), ops.to_nchw(dys[4]).cpu().transpose(0, 1), padding=1).transpose(0, 1)
     got = dsts_b[4].cpu()
     assert float((got.double() - want.double()).abs().max() / want.double().abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize('c,h,w', [(3, 37, 53), (1, 8, 8), (4, 16, 20), (6, 9, 9), (70, 5, 7)])
+def test_nchw_to_nhwc_layouts(dev, c, h, w):
+    """cat_nchw_to_nhwc: the C <= 4 pixel-per-lane form (RGB batches of set_input, pixel stride 4, padding channel zero) and the tiled transpose,
+    against a permute on the host; round trip through cat_nhwc_to_nchw."""
+    from cat_amd import ops
+    x = torch.randn(3, c, h, w, generator=torch.Generator().manual_seed(c * 100 + h))
+    y = ops.to_nhwc(x.to(dev))
+    cs = ops.act_cs(y)
+    raw = torch.as_strided(y, (3, h, w, cs), (h * w * cs, w * cs, cs, 1)).cpu()
+    assert torch.equal(raw[..., :c], x.permute(0, 2, 3, 1))
+    if cs > c:
+        assert float(raw[..., c:].abs().max()) == 0.0
+    assert torch.equal(ops.to_nchw(y).cpu(), x)
